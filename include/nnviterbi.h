@@ -1,0 +1,168 @@
+/*
+ * nnviterbi.h -- C ABI of the MI355X-native neural Viterbi decode path.
+ *
+ * This is the drop-in boundary for ONE path of
+ * enessinanparildi/Neural-Network-Based-Viterbi-Decoding: the batched
+ * feed-forward forward-pass decoder
+ *     received soft bits -> (dense -> +bias -> tanh) x depth -> argmax -> bits
+ * The reference has no FFI of its own (it is pure Python on TensorFlow 1.x);
+ * the Python call sites each entry point stands in for are cited per function
+ * as  src/<file>:<lines>  relative to the reference tree.  The Python-side
+ * binding (ctypes) is shown in INTEGRATION.md and implemented in
+ * neural-network-based-viterbi-decoding_amd/_cabi.py.
+ *
+ * Conventions
+ *   - plain C types only; every buffer is owned by the caller;
+ *   - pointers named *_dev are device (HBM) pointers, *_host are host pointers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     every launch is stream-ordered and returns without synchronising;
+ *   - every function returns an nnv_status (0 = NNV_OK); no exceptions, no
+ *     global mutable state besides a per-process kernel-attribute cache;
+ *   - there is NO CPU fallback: without a HIP device every compute entry
+ *     point returns NNV_ERR_NO_DEVICE / the HIP error.
+ */
+#ifndef NNVITERBI_H_
+#define NNVITERBI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNV_ABI_VERSION 1
+#define NNV_MAX_LAYERS 4 /* dense layers incl. the output layer */
+
+typedef enum nnv_status {
+  NNV_OK = 0,
+  NNV_ERR_INVALID_ARGUMENT = 1, /* NULL where not allowed, bad sizes        */
+  NNV_ERR_UNSUPPORTED_SHAPE = 2, /* no kernel instantiation for this network */
+  NNV_ERR_NO_DEVICE = 3,         /* no HIP device / wrong architecture       */
+  NNV_ERR_HIP = 4,               /* a HIP runtime call failed                */
+  NNV_ERR_OUT_OF_MEMORY = 5
+} nnv_status;
+
+/* Convolutional codes of the reference's generators. */
+typedef enum nnv_code {
+  NNV_CODE_57 = 0,     /* encode_57,     src/fnn_viterbi.py:122-154 (quirks kept) */
+  NNV_CODE_133171 = 1  /* encode_133171, src/fnn_viterbi.py:157-217               */
+} nnv_code;
+
+/*
+ * Network description: the reference's weights/biases dictionaries
+ * (initialize_weights, src/fnn_viterbi.py:413-468): depth dense layers,
+ * W[l] is [dims[l]][dims[l+1]] row-major fp32 (right-multiply x @ W),
+ * b[l] is [dims[l+1]] fp32.  dims[0] = n_input, dims[depth] = n_classes.
+ * All pointers are HOST pointers (the whole network is <= 0.3 MB).
+ */
+typedef struct nnv_mlp_desc {
+  int32_t depth;                    /* 2..NNV_MAX_LAYERS                     */
+  int32_t dims[NNV_MAX_LAYERS + 1];
+  const float *W_host[NNV_MAX_LAYERS];
+  const float *b_host[NNV_MAX_LAYERS];
+} nnv_mlp_desc;
+
+/* Opaque: weights re-laid-out in MFMA A-fragment order, resident in HBM. */
+typedef struct nnv_mlp_handle nnv_mlp_handle;
+
+/* ABI version of the loaded library (== NNV_ABI_VERSION of its header). */
+int32_t nnv_abi_version(void);
+
+/* Static, NUL-terminated description of a status code. */
+const char *nnv_status_string(int32_t status);
+
+/* Number of visible gfx950 devices (0 if none); never fails. */
+int32_t nnv_device_count(void);
+
+/*
+ * Replaces: building the TF variables + graph for multilayer_perceptron
+ * (src/fnn_viterbi.py:538-545; src/fnn_viterbi_mixed_snr.py:712-720) and
+ * tf.train.Saver.restore (mixed_snr:809-811).  Packs the network for the
+ * current device and uploads it.  Synchronous.  *out must be released with
+ * nnv_mlp_free.
+ */
+int32_t nnv_mlp_prepack(const nnv_mlp_desc *net, nnv_mlp_handle **out);
+
+int32_t nnv_mlp_free(nnv_mlp_handle *h);
+
+/*
+ * THE HOT PATH.  Replaces
+ *   predictions = tf.argmax(multilayer_perceptron(x, W, b), 1).eval({x: test_set})
+ *     src/fnn_viterbi.py:494-510,606-610; src/fnn_viterbi_mixed_snr.py:589-592,787-791,813-818,833
+ *   np.binary_repr(pred, width=b) per row        src/fnn_viterbi.py:648-651
+ *   the BER/FER counting loops                   src/fnn_viterbi.py:639,654-667;
+ *                                                src/fnn_viterbi_mixed_snr.py:326-328,650-655
+ * in one fused launch.
+ *
+ *  x_dev        [n_rows][dims[0]] fp32, C-contiguous, 4-byte aligned
+ *  labels_dev   nullable [n_rows] int32 true class per row
+ *  cls32_dev    nullable [n_rows] int32 decoded class (argmax, first maximum)
+ *  cls64_dev    nullable [n_rows] int64 the same, in tf.argmax's dtype
+ *  bits_dev     nullable [n_rows][tile_bits] uint8, MSB first
+ *  counters_dev nullable uint64[4] {bit_errors, frame_errors, total_bits,
+ *               total_frames}; the launch ADDS to them (zero them once, run
+ *               many launches); requires labels_dev
+ *  tile_bits    b; must satisfy 2^b >= dims[depth] for bits/counters
+ * n_rows == 0 is a no-op returning NNV_OK.
+ */
+int32_t nnv_mlp_decode_f32(const nnv_mlp_handle *h, const float *x_dev,
+                           int64_t n_rows, int32_t tile_bits,
+                           const int32_t *labels_dev, int32_t *cls32_dev,
+                           int64_t *cls64_dev, uint8_t *bits_dev,
+                           uint64_t *counters_dev, void *stream);
+
+/*
+ * Debug / parity entry: the tanh'd output layer itself,
+ * multilayer_perceptron(x, W, b) (src/fnn_viterbi.py:471-510).
+ *  out_dev  [n_rows][dims[depth]] fp32.  Slow (strided stores).
+ */
+int32_t nnv_mlp_forward_f32(const nnv_mlp_handle *h, const float *x_dev,
+                            int64_t n_rows, float *out_dev, void *stream);
+
+/*
+ * Synthetic input generator (benchmark harness and on-device data path).
+ * Replaces the per-row Python loops of train_test_dataset
+ * (src/fnn_viterbi.py:343-388) for random (not class-major) rows: row r of
+ * the GLOBAL stream (r = first_row + local index) draws tile_bits info bits
+ * and 2*tile_bits Gaussian samples from Philox4x32-10 keyed by (seed, r), so
+ * the data do not depend on how rows are sharded over GPUs; the bits are
+ * encoded from zero state with `code` exactly like the reference encodes a
+ * class (src/fnn_viterbi.py:351-352), BPSK-mapped (0 -> -1, 1 -> +1,
+ * src/fnn_viterbi.py:244-247) and sigma * N(0,1) is added
+ * (src/fnn_viterbi.py:250-251).
+ *
+ *  sigma_host      n_sigma standard deviations; block i = r / rows_per_block
+ *                  uses sigma_host[i % n_sigma] (config 4's mixed-SNR sweep;
+ *                  n_sigma == 1 for a single SNR)
+ *  x_dev           [n_rows][2*tile_bits] fp32 out
+ *  labels_dev      nullable [n_rows] int32 out: class index, MSB-first value
+ *                  of the info bits (src/fnn_viterbi.py:281-285)
+ */
+int32_t nnv_awgn_generate_f32(int32_t code, int32_t tile_bits, int64_t n_rows,
+                              int64_t first_row, int64_t rows_per_block,
+                              const float *sigma_host, int32_t n_sigma,
+                              uint64_t seed, float *x_dev, int32_t *labels_dev,
+                              void *stream);
+
+/*
+ * Timing helper used by bench.py: launches nnv_mlp_decode_f32 `iters` times
+ * back-to-back on `stream` between two HIP events recorded on that same
+ * stream and returns the elapsed milliseconds (synchronises the stream).
+ */
+int32_t nnv_mlp_decode_f32_timed(const nnv_mlp_handle *h, const float *x_dev,
+                                 int64_t n_rows, int32_t tile_bits,
+                                 const int32_t *labels_dev, int32_t *cls32_dev,
+                                 uint64_t *counters_dev, void *stream,
+                                 int32_t iters, float *elapsed_ms_host);
+
+/* Introspection: fills info_host[0..7] = {threads per workgroup, workgroups
+ * launched for n_rows, dynamic LDS bytes, VGPRs (0 if unknown), weights
+ * resident in LDS (1/0 for the output layer), rows per wave tile, depth,
+ * n_classes}. */
+int32_t nnv_mlp_launch_info(const nnv_mlp_handle *h, int64_t n_rows,
+                            int32_t *info_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNVITERBI_H_ */

@@ -1,0 +1,108 @@
+"""ctypes binding of the C ABI declared in include/nnviterbi.h.
+
+This is the only place the package touches native code.  There is no CPU
+fallback: if ``libnnviterbi_hip.so`` is missing or no gfx950 device is
+present, the compute entry points raise ``NNViterbiError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG_DIR, "libnnviterbi_hip.so")
+_CSRC = os.path.join(_PKG_DIR, "csrc")
+
+NNV_ABI_VERSION = 1
+NNV_MAX_LAYERS = 4
+NNV_OK = 0
+NNV_CODE_57 = 0
+NNV_CODE_133171 = 1
+
+EXPORTED_SYMBOLS = (
+    "nnv_abi_version", "nnv_status_string", "nnv_device_count",
+    "nnv_mlp_prepack", "nnv_mlp_free", "nnv_mlp_decode_f32",
+    "nnv_mlp_forward_f32", "nnv_awgn_generate_f32",
+    "nnv_mlp_decode_f32_timed", "nnv_mlp_launch_info",
+)
+
+
+class NNViterbiError(RuntimeError):
+    """A C-ABI call failed, or the HIP library is not available."""
+
+
+class MlpDesc(ctypes.Structure):
+    _fields_ = [
+        ("depth", ctypes.c_int32),
+        ("dims", ctypes.c_int32 * (NNV_MAX_LAYERS + 1)),
+        ("W_host", ctypes.c_void_p * NNV_MAX_LAYERS),
+        ("b_host", ctypes.c_void_p * NNV_MAX_LAYERS),
+    ]
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def build_library(force: bool = False, jobs: int = 4) -> str:
+    """Compile csrc/*.hip for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, f"-j{jobs}", "-s"]
+    if force:
+        args.append("-B")
+    subprocess.run(args, check=True)
+    return _LIB_PATH
+
+
+def load_library() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise NNViterbiError(
+            f"{_LIB_PATH} is missing: build it with __graft_entry__.build() "
+            "(make -C neural-network-based-viterbi-decoding_amd/csrc). "
+            "There is no CPU fallback for the decode path.")
+    lib = ctypes.CDLL(_LIB_PATH)
+    c = ctypes
+    lib.nnv_abi_version.restype = c.c_int32
+    lib.nnv_abi_version.argtypes = []
+    lib.nnv_status_string.restype = c.c_char_p
+    lib.nnv_status_string.argtypes = [c.c_int32]
+    lib.nnv_device_count.restype = c.c_int32
+    lib.nnv_device_count.argtypes = []
+    lib.nnv_mlp_prepack.restype = c.c_int32
+    lib.nnv_mlp_prepack.argtypes = [c.POINTER(MlpDesc), c.POINTER(c.c_void_p)]
+    lib.nnv_mlp_free.restype = c.c_int32
+    lib.nnv_mlp_free.argtypes = [c.c_void_p]
+    lib.nnv_mlp_decode_f32.restype = c.c_int32
+    lib.nnv_mlp_decode_f32.argtypes = [
+        c.c_void_p, c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_void_p,
+        c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.nnv_mlp_forward_f32.restype = c.c_int32
+    lib.nnv_mlp_forward_f32.argtypes = [
+        c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+    lib.nnv_awgn_generate_f32.restype = c.c_int32
+    lib.nnv_awgn_generate_f32.argtypes = [
+        c.c_int32, c.c_int32, c.c_int64, c.c_int64, c.c_int64, c.c_void_p,
+        c.c_int32, c.c_uint64, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.nnv_mlp_decode_f32_timed.restype = c.c_int32
+    lib.nnv_mlp_decode_f32_timed.argtypes = [
+        c.c_void_p, c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_void_p,
+        c.c_void_p, c.c_void_p, c.c_int32, c.POINTER(c.c_float)]
+    lib.nnv_mlp_launch_info.restype = c.c_int32
+    lib.nnv_mlp_launch_info.argtypes = [c.c_void_p, c.c_int64, c.POINTER(c.c_int32)]
+    if lib.nnv_abi_version() != NNV_ABI_VERSION:
+        raise NNViterbiError(
+            f"ABI mismatch: library {lib.nnv_abi_version()} != binding {NNV_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != NNV_OK:
+        msg = load_library().nnv_status_string(status).decode()
+        raise NNViterbiError(f"{what} failed: {msg} (status {status})")

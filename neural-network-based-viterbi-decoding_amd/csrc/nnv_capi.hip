@@ -1,0 +1,283 @@
+// C ABI of libnnviterbi_hip.so (declared in include/nnviterbi.h).
+// Host-side only: argument validation, weight pre-packing, launch planning.
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "nnv_internal.h"
+
+using nnv::DecodeParams;
+using nnv::LaunchPlan;
+using nnv::PackedShape;
+
+namespace {
+
+constexpr int kLdsLimitBytes = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may own all of it
+
+bool is_gfx950(const hipDeviceProp_t &prop) { return strstr(prop.gcnArchName, "gfx950") != nullptr; }
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+nnv_status shape_from_desc(const nnv_mlp_desc *net, PackedShape *s) {
+  if (net->depth < 2 || net->depth > NNV_MAX_LAYERS) return NNV_ERR_UNSUPPORTED_SHAPE;
+  for (int l = 0; l <= net->depth; ++l)
+    if (net->dims[l] < 1) return NNV_ERR_INVALID_ARGUMENT;
+  for (int l = 0; l < net->depth; ++l)
+    if (!net->W_host[l] || !net->b_host[l]) return NNV_ERR_INVALID_ARGUMENT;
+  memset(s, 0, sizeof(*s));
+  s->depth = net->depth;
+  s->nhid = net->depth - 1;
+  s->n_in = net->dims[0];
+  s->bp = ceil_div(s->n_in, 2);
+  s->g1 = ceil_div(s->bp, 4);
+  for (int i = 0; i < s->nhid; ++i) s->mt[i] = ceil_div(net->dims[i + 1], 32);
+  s->n_classes = net->dims[net->depth];
+  s->mt_out = ceil_div(s->n_classes, 32);
+  s->kt_out = s->mt[s->nhid - 1];
+  s->hid_floats = static_cast<int64_t>(s->mt[0]) * s->g1 * nnv::kFragGroupFloats;
+  for (int i = 1; i < s->nhid; ++i)
+    s->hid_floats += static_cast<int64_t>(s->mt[i]) * s->mt[i - 1] * 4 * nnv::kFragGroupFloats;
+  s->out_floats = static_cast<int64_t>(s->mt_out) * s->kt_out * 4 * nnv::kFragGroupFloats;
+  int mts = s->mt_out;
+  for (int i = 0; i < s->nhid; ++i) mts += s->mt[i];
+  s->bias_floats = 32LL * mts;
+  return nnv::decode_supported(*s);
+}
+
+// Fragment order: see nnv_internal.h.
+void pack_network(const nnv_mlp_desc *net, const PackedShape &s, std::vector<float> *out) {
+  out->assign(static_cast<size_t>(s.hid_floats + s.out_floats + s.bias_floats), 0.f);
+  float *w = out->data();
+  // layer 1
+  {
+    const int M = net->dims[1];
+    const float *W = net->W_host[0];
+    for (int mt = 0; mt < s.mt[0]; ++mt)
+      for (int g = 0; g < s.g1; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 4; ++e) {
+            const int step = 4 * g + e;
+            const int k = (lane >> 5) * s.bp + step;
+            const int i = 32 * mt + (lane & 31);
+            const bool ok = step < s.bp && k < s.n_in && i < M;
+            *w++ = ok ? W[static_cast<size_t>(k) * M + i] : 0.f;
+          }
+  }
+  // layers 2..depth (the last one is the output layer; same fragment rule)
+  for (int l = 1; l < net->depth; ++l) {
+    const int K = net->dims[l], M = net->dims[l + 1];
+    const int KT = s.mt[l - 1];
+    const int MT = (l == net->depth - 1) ? s.mt_out : s.mt[l];
+    const float *W = net->W_host[l];
+    for (int mt = 0; mt < MT; ++mt)
+      for (int kt = 0; kt < KT; ++kt)
+        for (int q = 0; q < 4; ++q)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 4; ++e) {
+              const int k = 32 * kt + e + 8 * q + 4 * (lane >> 5);
+              const int i = 32 * mt + (lane & 31);
+              const bool ok = k < K && i < M;
+              *w++ = ok ? W[static_cast<size_t>(k) * M + i] : 0.f;
+            }
+  }
+  // biases, each layer padded to a multiple of 32
+  for (int l = 0; l < net->depth; ++l) {
+    const int M = net->dims[l + 1];
+    const int MT = (l == net->depth - 1) ? s.mt_out : s.mt[l];
+    for (int i = 0; i < 32 * MT; ++i) *w++ = i < M ? net->b_host[l][i] : 0.f;
+  }
+}
+
+nnv_status make_params(const nnv_mlp_handle *h, const float *x_dev, int64_t n_rows,
+                       DecodeParams *p, LaunchPlan *plan) {
+  const PackedShape &s = h->shape;
+  const nnv_status st = nnv::decode_plan(s, n_rows, h->num_cus, h->lds_limit, plan);
+  if (st != NNV_OK) return st;
+  memset(p, 0, sizeof(*p));
+  p->x = x_dev;
+  p->n_rows = n_rows;
+  p->n_tiles = (n_rows + nnv::kRowsPerTile - 1) / nnv::kRowsPerTile;
+  p->wpack = h->wpack_dev;
+  p->n_in = s.n_in;
+  p->bp = s.bp;
+  p->xvec = (s.n_in == 2 * s.bp) && (s.bp % 4 == 0) &&
+            (reinterpret_cast<uintptr_t>(x_dev) % 16 == 0);
+  p->mt_out = s.mt_out;
+  p->n_classes = s.n_classes;
+  p->out_in_lds = plan->out_in_lds;
+  return NNV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t nnv_abi_version(void) { return NNV_ABI_VERSION; }
+
+const char *nnv_status_string(int32_t status) {
+  switch (status) {
+    case NNV_OK: return "ok";
+    case NNV_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case NNV_ERR_UNSUPPORTED_SHAPE: return "unsupported network shape (no kernel instantiation)";
+    case NNV_ERR_NO_DEVICE: return "no gfx950 HIP device";
+    case NNV_ERR_HIP: return "HIP runtime error";
+    case NNV_ERR_OUT_OF_MEMORY: return "out of memory";
+    default: return "unknown status";
+  }
+}
+
+int32_t nnv_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int d = 0; d < n; ++d) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) == hipSuccess && is_gfx950(prop)) ++ok;
+  }
+  return ok;
+}
+
+int32_t nnv_mlp_prepack(const nnv_mlp_desc *net, nnv_mlp_handle **out) {
+  if (!net || !out) return NNV_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  PackedShape s;
+  const nnv_status st = shape_from_desc(net, &s);
+  if (st != NNV_OK) return st;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return NNV_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NNV_ERR_NO_DEVICE;
+  if (!is_gfx950(prop)) return NNV_ERR_NO_DEVICE;
+  if ((s.hid_floats + s.bias_floats) * 4 > kLdsLimitBytes) return NNV_ERR_UNSUPPORTED_SHAPE;
+
+  std::vector<float> packed;
+  pack_network(net, s, &packed);
+  nnv_mlp_handle *h = new (std::nothrow) nnv_mlp_handle;
+  if (!h) return NNV_ERR_OUT_OF_MEMORY;
+  h->shape = s;
+  for (int l = 0; l <= NNV_MAX_LAYERS; ++l) h->dims[l] = l <= net->depth ? net->dims[l] : 0;
+  h->wpack_floats = static_cast<int64_t>(packed.size());
+  h->device = dev;
+  h->num_cus = prop.multiProcessorCount;
+  h->lds_limit = kLdsLimitBytes;
+  h->wpack_dev = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&h->wpack_dev), packed.size() * sizeof(float)) != hipSuccess) {
+    delete h;
+    return NNV_ERR_OUT_OF_MEMORY;
+  }
+  if (hipMemcpy(h->wpack_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(h->wpack_dev);
+    delete h;
+    return NNV_ERR_HIP;
+  }
+  *out = h;
+  return NNV_OK;
+}
+
+int32_t nnv_mlp_free(nnv_mlp_handle *h) {
+  if (!h) return NNV_OK;
+  const hipError_t e = hipFree(h->wpack_dev);
+  delete h;
+  return e == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+}
+
+int32_t nnv_mlp_decode_f32(const nnv_mlp_handle *h, const float *x_dev, int64_t n_rows,
+                           int32_t tile_bits, const int32_t *labels_dev, int32_t *cls32_dev,
+                           int64_t *cls64_dev, uint8_t *bits_dev, uint64_t *counters_dev,
+                           void *stream) {
+  if (!h || n_rows < 0) return NNV_ERR_INVALID_ARGUMENT;
+  if (n_rows == 0) return NNV_OK;
+  if (!x_dev) return NNV_ERR_INVALID_ARGUMENT;
+  if (counters_dev && !labels_dev) return NNV_ERR_INVALID_ARGUMENT;
+  if (bits_dev || counters_dev) {
+    if (tile_bits < 1 || tile_bits > 30) return NNV_ERR_INVALID_ARGUMENT;
+    if ((1LL << tile_bits) < h->shape.n_classes) return NNV_ERR_INVALID_ARGUMENT;
+  }
+  DecodeParams p;
+  LaunchPlan plan;
+  const nnv_status st = make_params(h, x_dev, n_rows, &p, &plan);
+  if (st != NNV_OK) return st;
+  p.tile_bits = tile_bits;
+  p.labels = labels_dev;
+  p.cls32 = cls32_dev;
+  p.cls64 = cls64_dev;
+  p.bits = bits_dev;
+  p.counters = reinterpret_cast<unsigned long long *>(counters_dev);
+  return nnv::decode_launch(h->shape, p, plan, false, static_cast<hipStream_t>(stream));
+}
+
+int32_t nnv_mlp_forward_f32(const nnv_mlp_handle *h, const float *x_dev, int64_t n_rows,
+                            float *out_dev, void *stream) {
+  if (!h || n_rows < 0) return NNV_ERR_INVALID_ARGUMENT;
+  if (n_rows == 0) return NNV_OK;
+  if (!x_dev || !out_dev) return NNV_ERR_INVALID_ARGUMENT;
+  DecodeParams p;
+  LaunchPlan plan;
+  const nnv_status st = make_params(h, x_dev, n_rows, &p, &plan);
+  if (st != NNV_OK) return st;
+  p.act = out_dev;
+  return nnv::decode_launch(h->shape, p, plan, true, static_cast<hipStream_t>(stream));
+}
+
+int32_t nnv_awgn_generate_f32(int32_t code, int32_t tile_bits, int64_t n_rows, int64_t first_row,
+                              int64_t rows_per_block, const float *sigma_host, int32_t n_sigma,
+                              uint64_t seed, float *x_dev, int32_t *labels_dev, void *stream) {
+  if (n_rows < 0 || first_row < 0 || rows_per_block < 1) return NNV_ERR_INVALID_ARGUMENT;
+  if (!sigma_host || n_sigma < 1 || n_sigma > 16) return NNV_ERR_INVALID_ARGUMENT;
+  // the reference encoders index bits[5] / bits[1] unconditionally
+  // (src/fnn_viterbi.py:143,201): shorter blocks are an error there too
+  if (code == NNV_CODE_133171) {
+    if (tile_bits < 6) return NNV_ERR_INVALID_ARGUMENT;
+  } else if (code == NNV_CODE_57) {
+    if (tile_bits < 2) return NNV_ERR_INVALID_ARGUMENT;
+  } else {
+    return NNV_ERR_INVALID_ARGUMENT;
+  }
+  if (tile_bits > 16) return NNV_ERR_INVALID_ARGUMENT;
+  if (n_rows == 0) return NNV_OK;
+  if (!x_dev) return NNV_ERR_INVALID_ARGUMENT;
+  return nnv::generate_launch(code, tile_bits, n_rows, first_row, rows_per_block, sigma_host,
+                              n_sigma, seed, x_dev, labels_dev, static_cast<hipStream_t>(stream));
+}
+
+int32_t nnv_mlp_decode_f32_timed(const nnv_mlp_handle *h, const float *x_dev, int64_t n_rows,
+                                 int32_t tile_bits, const int32_t *labels_dev, int32_t *cls32_dev,
+                                 uint64_t *counters_dev, void *stream, int32_t iters,
+                                 float *elapsed_ms_host) {
+  if (!elapsed_ms_host || iters < 1) return NNV_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess) return NNV_ERR_HIP;
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return NNV_ERR_HIP; }
+  int32_t st = NNV_OK;
+  if (hipEventRecord(e0, s) != hipSuccess) st = NNV_ERR_HIP;
+  for (int i = 0; i < iters && st == NNV_OK; ++i)
+    st = nnv_mlp_decode_f32(h, x_dev, n_rows, tile_bits, labels_dev, cls32_dev, nullptr, nullptr,
+                            counters_dev, stream);
+  if (st == NNV_OK && hipEventRecord(e1, s) != hipSuccess) st = NNV_ERR_HIP;
+  if (st == NNV_OK && hipEventSynchronize(e1) != hipSuccess) st = NNV_ERR_HIP;
+  if (st == NNV_OK && hipEventElapsedTime(elapsed_ms_host, e0, e1) != hipSuccess) st = NNV_ERR_HIP;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return st;
+}
+
+int32_t nnv_mlp_launch_info(const nnv_mlp_handle *h, int64_t n_rows, int32_t *info_host) {
+  if (!h || !info_host || n_rows < 0) return NNV_ERR_INVALID_ARGUMENT;
+  LaunchPlan plan;
+  const nnv_status st = nnv::decode_plan(h->shape, n_rows, h->num_cus, h->lds_limit, &plan);
+  if (st != NNV_OK) return st;
+  info_host[0] = plan.threads;
+  info_host[1] = plan.blocks;
+  info_host[2] = plan.lds_bytes;
+  info_host[3] = nnv::decode_kernel_vgprs(h->shape);
+  info_host[4] = plan.out_in_lds;
+  info_host[5] = nnv::kRowsPerTile;
+  info_host[6] = h->shape.depth;
+  info_host[7] = h->shape.n_classes;
+  return NNV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Internal declarations shared by the translation units of libnnviterbi_hip.so.
+// Not part of the public ABI (that is include/nnviterbi.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nnviterbi.h"
+
+namespace nnv {
+
+// ---------------------------------------------------------------------------
+// Packed network layout (built on the host by prepack, read by the kernel)
+//
+// One MFMA v_mfma_f32_32x32x2_f32 step consumes, per lane l, ONE fp32 of the
+// A operand: A[i = l & 31][k = l >> 5].  We compute the transposed problem
+//     H_l^T [neurons x rows] = W_l^T [neurons x K] * H_{l-1}^T [K x rows]
+// so A fragments are weights and the B operand is the previous layer's
+// accumulator register as it stands (see nnv_mlp_decode.hip).
+//
+// A "fragment group" is 64 lanes x 4 consecutive steps = 256 floats, stored
+// [lane][4] so that one ds_read_b128 / global_load_dwordx4 per lane fetches
+// the A operands of 4 MFMAs.
+//
+//  layer 1   groups [mt][g]      g < G1      step s = 4g+e uses input
+//                                            k = (l>>5)*bp + s   (bp = ceil(n_in/2))
+//  layer >=2 groups [mt][kt][q]  q < 4       step r = 4q+e uses input neuron
+//                                            k = 32kt + e + 8q + 4(l>>5)
+//            (exactly the neuron that register r of M-tile kt of the previous
+//             layer's 32x32 accumulator holds in that lane half)
+//  value     W[k][32mt + (l&31)]  (0 where k or the neuron is padding)
+//
+// wpack = [hidden layers' groups][output layer's groups][biases, each layer
+// padded to 32*MT floats]
+// ---------------------------------------------------------------------------
+constexpr int kFragGroupFloats = 256;
+constexpr int kRowsPerTile = 32;  // batch rows per wave tile (MFMA N dim)
+
+struct PackedShape {
+  int32_t depth;        // dense layers incl. output
+  int32_t nhid;         // depth - 1
+  int32_t n_in;         // dims[0]
+  int32_t bp;           // ceil(n_in / 2): layer-1 K steps actually used
+  int32_t g1;           // ceil(bp / 4): layer-1 fragment groups per M-tile
+  int32_t mt[3];        // hidden layers' M-tiles (width padded to 32)
+  int32_t n_classes;    // dims[depth]
+  int32_t mt_out;       // ceil(n_classes / 32)
+  int32_t kt_out;       // mt[nhid-1]
+  int64_t hid_floats;   // floats of all hidden-layer groups
+  int64_t out_floats;   // floats of the output-layer groups
+  int64_t bias_floats;  // 32 * (sum mt + mt_out)
+};
+
+struct DecodeParams {
+  const float *x;
+  int64_t n_rows;
+  int64_t n_tiles;
+  const float *wpack;  // device
+  int32_t n_in;
+  int32_t bp;
+  int32_t xvec;        // 1: 16-byte vector loads of x are legal
+  int32_t mt_out;
+  int32_t n_classes;
+  int32_t out_in_lds;  // output-layer groups are LDS resident
+  int32_t tile_bits;
+  const int32_t *labels;
+  int32_t *cls32;
+  int64_t *cls64;
+  uint8_t *bits;
+  float *act;
+  unsigned long long *counters;
+};
+
+struct LaunchPlan {
+  int32_t threads;
+  int32_t blocks;
+  int32_t lds_bytes;
+  int32_t out_in_lds;
+};
+
+// nnv_mlp_decode.hip
+nnv_status decode_supported(const PackedShape &s);
+nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
+                       int lds_limit, LaunchPlan *plan);
+nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
+                         const LaunchPlan &plan, bool write_act,
+                         hipStream_t stream);
+int decode_kernel_vgprs(const PackedShape &s);
+
+// nnv_generator.hip
+nnv_status generate_launch(int32_t code, int32_t tile_bits, int64_t n_rows,
+                           int64_t first_row, int64_t rows_per_block,
+                           const float *sigma, int32_t n_sigma, uint64_t seed,
+                           float *x, int32_t *labels, hipStream_t stream);
+
+}  // namespace nnv
+
+struct nnv_mlp_handle {
+  nnv::PackedShape shape;
+  int32_t dims[NNV_MAX_LAYERS + 1];
+  float *wpack_dev;
+  int64_t wpack_floats;
+  int device;
+  int num_cus;
+  int lds_limit;
+};

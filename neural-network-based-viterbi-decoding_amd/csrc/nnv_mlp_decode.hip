@@ -1,0 +1,433 @@
+// Fused feed-forward neural Viterbi decode kernel for gfx950 (MI355X).
+//
+// Replaces, in ONE launch, the reference's
+//   multilayer_perceptron   src/fnn_viterbi.py:494-510   (matmul,+bias,tanh) x depth
+//   tf.argmax(pred, 1)      src/fnn_viterbi.py:606-610   first maximum
+//   np.binary_repr per row  src/fnn_viterbi.py:648-651   MSB-first bits
+//   BER / FER loops         src/fnn_viterbi.py:639,654-667
+//
+// Design (MI355X-first, see DESIGN.md "K1"):
+//  * The problem is computed TRANSPOSED on the fp32 matrix cores
+//    (v_mfma_f32_32x32x2_f32, exact fp32 fmaf chain):
+//        H_l^T[neurons x 32 rows] = W_l^T * H_{l-1}^T
+//    A wave owns a tile of 32 received blocks (rows).  The 32x32 accumulator
+//    of layer l has the ROW (received block) on the lane and the neuron in the
+//    register, which is exactly the B-operand layout of the next layer's MFMA
+//    if the weights are stored in the matching k order.  So activations never
+//    leave the register file: no LDS round trip, no cross-lane traffic, until
+//    the final 2-lane argmax merge.
+//  * Weights (A operands) are pre-packed on the host in fragment order and are
+//    LDS resident (one copy per CU, shared by all waves of a persistent
+//    workgroup); one ds_read_b128 feeds 4 MFMAs.  An output layer too large
+//    for the 160 KiB LDS is streamed from L2 with coalesced dwordx4 loads.
+//  * bias add + tanh (v_exp_f32 / v_rcp_f32) + running first-max argmax run on
+//    the VALU in the shadow of the MFMA pipe (several waves per SIMD).
+//  * Received soft bits are read once, as per-lane contiguous half rows
+//    (a wave reads one contiguous 32*n_in*4-byte span), prefetched one tile
+//    ahead; decoded classes are written as one 128-byte store per tile.
+#include "nnv_internal.h"
+
+namespace nnv {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// tanh(z) = 1 - 2 / (1 + e^{2z});  e^{2z} = 2^{z * 2 log2(e)}.
+// v_exp_f32 and v_rcp_f32 are 1-ulp hardware approximations; the absolute
+// error of the result is <= ~2.5e-7 over the whole real line (measured in
+// tests/test_gpu_parity.py::test_tanh_accuracy), and the limits are exact:
+// z -> +inf gives rcp(inf) = 0 -> 1, z -> -inf gives rcp(1) = 1 -> -1.
+__device__ __forceinline__ float tanh_f32(float z) {
+  const float e = __builtin_amdgcn_exp2f(z * 2.8853900817779268f);
+  const float r = __builtin_amdgcn_rcpf(1.0f + e);
+  return __builtin_fmaf(-2.0f, r, 1.0f);
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// acc register r = 4q+e of a 32x32 tile holds neuron 8q + 4*(lane>>5) + e of
+// that M-tile; bias vectors are stored padded to 32 floats per M-tile, so one
+// 16-byte read per q fetches the 4 biases this lane needs.
+template <typename BiasPtr>
+__device__ __forceinline__ void bias_tanh(f32x16 &acc, BiasPtr bias_tile,
+                                          int half) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_tile + 8 * q + 4 * half);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[4 * q + e] = tanh_f32(acc[4 * q + e] + bv[e]);
+  }
+}
+
+template <int G1>
+__device__ __forceinline__ void load_x(const DecodeParams &p, int64_t tile,
+                                       int j, int half, float (&xr)[4 * G1]) {
+  int64_t row = tile * kRowsPerTile + j;
+  row = row < p.n_rows ? row : p.n_rows - 1;  // tail rows: valid memory, discarded
+  const float *px = p.x + row * p.n_in + half * p.bp;
+  if (p.xvec) {
+#pragma unroll
+    for (int g = 0; g < G1; ++g) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (4 * g < p.bp) v = *reinterpret_cast<const f32x4 *>(px + 4 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xr[4 * g + e] = v[e];
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4 * G1; ++s) {
+      const bool ok = (s < p.bp) && (half * p.bp + s < p.n_in);
+      xr[s] = ok ? px[s] : 0.f;
+    }
+  }
+}
+
+template <int G1, int NHID, int MTA, int MTB, int MTC, int NT, bool WRITE_ACT>
+__global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int W1F = MTA * G1 * kFragGroupFloats;
+  constexpr int W2F = NHID >= 2 ? MTB * MTA * 4 * kFragGroupFloats : 0;
+  constexpr int W3F = NHID >= 3 ? MTC * MTB * 4 * kFragGroupFloats : 0;
+  constexpr int HIDF = W1F + W2F + W3F;
+  constexpr int KT_OUT = NHID == 1 ? MTA : (NHID == 2 ? MTB : MTC);
+  constexpr int B1OFF = HIDF;
+  constexpr int B2OFF = B1OFF + 32 * MTA;
+  constexpr int B3OFF = B2OFF + (NHID >= 2 ? 32 * MTB : 0);
+  constexpr int BOOFF = B3OFF + (NHID >= 3 ? 32 * MTC : 0);
+  constexpr int WAVES = NT / 64;
+
+  const int out_floats = p.mt_out * KT_OUT * 4 * kFragGroupFloats;
+  const int bias_floats = (BOOFF - HIDF) + 32 * p.mt_out;
+  const int lds_out = BOOFF + 32 * p.mt_out;  // output groups (if resident)
+
+  // ---- stage the packed network into LDS (once per persistent workgroup) --
+  {
+    const float *g_hid = p.wpack;
+    const float *g_out = p.wpack + HIDF;
+    const float *g_bias = p.wpack + HIDF + out_floats;
+    for (int i = threadIdx.x * 4; i < HIDF; i += NT * 4)
+      *reinterpret_cast<f32x4 *>(lds + i) = *reinterpret_cast<const f32x4 *>(g_hid + i);
+    for (int i = threadIdx.x * 4; i < bias_floats; i += NT * 4)
+      *reinterpret_cast<f32x4 *>(lds + HIDF + i) = *reinterpret_cast<const f32x4 *>(g_bias + i);
+    if (p.out_in_lds)
+      for (int i = threadIdx.x * 4; i < out_floats; i += NT * 4)
+        *reinterpret_cast<f32x4 *>(lds + lds_out + i) = *reinterpret_cast<const f32x4 *>(g_out + i);
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31;
+  const int half = lane >> 5;
+  const int64_t tstride = static_cast<int64_t>(gridDim.x) * WAVES;
+  int64_t tile = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
+
+  unsigned bit_err = 0, frame_err = 0;
+  float xr[4 * G1];
+  if (tile < p.n_tiles) load_x<G1>(p, tile, j, half, xr);
+
+  while (tile < p.n_tiles) {
+    const int64_t next_tile = tile + tstride;
+    float xn[4 * G1];
+    bool prefetched = false;
+    // The packed weights in LDS never change, so LLVM would hoist every
+    // fragment read out of this persistent loop (and spill them).  Making the
+    // lane offset opaque once per tile keeps the reads next to their MFMAs.
+    int lo = lane * 4;
+    asm volatile("" : "+v"(lo));
+
+    // ---------------- layer 1: K = n_in (bp steps of 2) -------------------
+    f32x16 ha[MTA];
+#pragma unroll
+    for (int mt = 0; mt < MTA; ++mt) {
+      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < G1; ++g) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(lds + (mt * G1 + g) * kFragGroupFloats + lo);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(a[e], xr[4 * g + e], acc);
+      }
+      bias_tanh(acc, lds + B1OFF + 32 * mt, half);
+      ha[mt] = acc;
+    }
+    if (NHID == 1) {
+      if (next_tile < p.n_tiles) load_x<G1>(p, next_tile, j, half, xn);
+      prefetched = true;
+    }
+
+    // ---------------- layer 2 ---------------------------------------------
+    f32x16 hb[NHID >= 2 ? MTB : 1];
+    if constexpr (NHID >= 2) {
+#pragma unroll
+      for (int mt = 0; mt < MTB; ++mt) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < MTA; ++kt) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(
+                lds + W1F + ((mt * MTA + kt) * 4 + q) * kFragGroupFloats + lo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma32(a[e], ha[kt][4 * q + e], acc);
+          }
+        }
+        bias_tanh(acc, lds + B2OFF + 32 * mt, half);
+        hb[mt] = acc;
+      }
+      if (!prefetched) {
+        if (next_tile < p.n_tiles) load_x<G1>(p, next_tile, j, half, xn);
+        prefetched = true;
+      }
+    }
+
+    // ---------------- layer 3 ---------------------------------------------
+    f32x16 hc[NHID >= 3 ? MTC : 1];
+    if constexpr (NHID >= 3) {
+#pragma unroll
+      for (int mt = 0; mt < MTC; ++mt) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < MTB; ++kt) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(
+                lds + W1F + W2F + ((mt * MTB + kt) * 4 + q) * kFragGroupFloats + lo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma32(a[e], hb[kt][4 * q + e], acc);
+          }
+        }
+        bias_tanh(acc, lds + B3OFF + 32 * mt, half);
+        hc[mt] = acc;
+      }
+    }
+
+    // ---------------- output layer + running first-max argmax -------------
+    auto &hlast = [&]() -> auto & {
+      if constexpr (NHID == 1) return ha;
+      else if constexpr (NHID == 2) return hb;
+      else return hc;
+    }();
+    float best = -__builtin_inff();
+    int bidx = 0;
+    const int64_t row = tile * kRowsPerTile + j;
+    for (int mt = 0; mt < p.mt_out; ++mt) {
+      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (p.out_in_lds) {
+        const float *wl = lds + lds_out + mt * KT_OUT * 4 * kFragGroupFloats + lo;
+#pragma unroll
+        for (int kt = 0; kt < KT_OUT; ++kt) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(wl + (kt * 4 + q) * kFragGroupFloats);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc = mfma32(a[e], hlast[kt][4 * q + e], acc);
+            }
+          }
+        }
+      } else {
+        const float *wg = p.wpack + HIDF + static_cast<int64_t>(mt) * KT_OUT * 4 * kFragGroupFloats + lo;
+#pragma unroll
+        for (int kt = 0; kt < KT_OUT; ++kt) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(wg + (kt * 4 + q) * kFragGroupFloats);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc = mfma32(a[e], hlast[kt][4 * q + e], acc);
+            }
+          }
+        }
+      }
+      bias_tanh(acc, lds + BOOFF + 32 * mt, half);
+      const int cbase = 32 * mt + 4 * half;
+      if (((mt + 1) * 32) <= p.n_classes) {
+        // per lane the class index grows with r, and mt grows outside: a
+        // strict > keeps the FIRST maximum of this lane's subset
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool c = acc[r] > best;
+          best = c ? acc[r] : best;
+          bidx = c ? cbase + 8 * (r >> 2) + (r & 3) : bidx;
+        }
+      } else {  // last tile of a class count that is not a multiple of 32
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = cbase + 8 * (r >> 2) + (r & 3);
+          const bool c = (ci < p.n_classes) && (acc[r] > best);
+          best = c ? acc[r] : best;
+          bidx = c ? ci : bidx;
+        }
+      }
+      if constexpr (WRITE_ACT) {
+        if (row < p.n_rows) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ci = cbase + 8 * (r >> 2) + (r & 3);
+            if (ci < p.n_classes) p.act[row * p.n_classes + ci] = acc[r];
+          }
+        }
+      }
+    }
+
+    // ---------------- merge the two lane halves, emit ----------------------
+    {
+      const float ov = __shfl_xor(best, 32);
+      const int oi = __shfl_xor(bidx, 32);
+      const bool take = (ov > best) || (ov == best && oi < bidx);
+      bidx = take ? oi : bidx;
+    }
+    if (half == 0 && row < p.n_rows) {
+      if (p.cls32) p.cls32[row] = bidx;
+      if (p.cls64) p.cls64[row] = bidx;
+      if (p.bits) {
+        uint8_t *pb = p.bits + row * p.tile_bits;
+        for (int t = 0; t < p.tile_bits; ++t)
+          pb[t] = static_cast<uint8_t>((bidx >> (p.tile_bits - 1 - t)) & 1);
+      }
+      if (p.labels) {
+        const unsigned diff = static_cast<unsigned>(bidx) ^ static_cast<unsigned>(p.labels[row]);
+        bit_err += __builtin_popcount(diff);
+        frame_err += diff != 0u;
+      }
+    }
+
+    if (next_tile < p.n_tiles) {
+#pragma unroll
+      for (int s = 0; s < 4 * G1; ++s) xr[s] = xn[s];
+    }
+    tile = next_tile;
+  }
+
+  // ---------------- error counters: one atomic pair per wave --------------
+  if (p.counters) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      bit_err += __shfl_xor(bit_err, off);
+      frame_err += __shfl_xor(frame_err, off);
+    }
+    if (lane == 0 && (bit_err | frame_err)) {
+      atomicAdd(p.counters + 0, static_cast<unsigned long long>(bit_err));
+      atomicAdd(p.counters + 1, static_cast<unsigned long long>(frame_err));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      atomicAdd(p.counters + 2, static_cast<unsigned long long>(p.n_rows) * p.tile_bits);
+      atomicAdd(p.counters + 3, static_cast<unsigned long long>(p.n_rows));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side: instantiation table, launch plan, launch
+// ---------------------------------------------------------------------------
+namespace {
+
+using KernelFn = void (*)(const DecodeParams);
+
+struct KernelEntry {
+  int g1, nhid, mta, mtb, mtc, nt;
+  bool act;
+  KernelFn fn;
+};
+
+#define NNV_K(G1, NHID, A, B, C, NT, ACT) \
+  { G1, NHID, A, B, C, NT, ACT, mlp_decode_kernel<G1, NHID, A, B, C, NT, ACT> }
+
+// The reference's networks: hidden widths are the first NHID of (128, 64, 32)
+// (src/fnn_viterbi.py:35-37) = M-tiles (4, 2, 1); n_in = 2b <= 24.
+#define NNV_FAMILY(G1)                                                       \
+  NNV_K(G1, 1, 4, 1, 1, 512, false), NNV_K(G1, 2, 4, 2, 1, 512, false),      \
+  NNV_K(G1, 3, 4, 2, 1, 512, false), NNV_K(G1, 1, 4, 1, 1, 1024, false),     \
+  NNV_K(G1, 2, 4, 2, 1, 1024, false), NNV_K(G1, 3, 4, 2, 1, 1024, false),    \
+  NNV_K(G1, 1, 4, 1, 1, 512, true), NNV_K(G1, 2, 4, 2, 1, 512, true),        \
+  NNV_K(G1, 3, 4, 2, 1, 512, true)
+
+const KernelEntry kKernels[] = {NNV_FAMILY(1), NNV_FAMILY(2), NNV_FAMILY(3)};
+
+const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act) {
+  const int mta = s.mt[0];
+  const int mtb = s.nhid >= 2 ? s.mt[1] : 1;
+  const int mtc = s.nhid >= 3 ? s.mt[2] : 1;
+  for (const KernelEntry &k : kKernels)
+    if (k.g1 == s.g1 && k.nhid == s.nhid && k.mta == mta && k.mtb == mtb &&
+        k.mtc == mtc && k.nt == nt && k.act == act)
+      return &k;
+  return nullptr;
+}
+
+// Workgroup size: 1024 threads = 4 waves per SIMD (<= 128 VGPRs) when that
+// instantiation does not spill, else 512 (2 per SIMD).  NNV_THREADS overrides
+// (tuning / A-B runs only).
+int pick_threads(const PackedShape &s) {
+  static const int forced = [] {
+    const char *e = getenv("NNV_THREADS");
+    const int v = e ? atoi(e) : 0;
+    return (v == 512 || v == 1024) ? v : 0;
+  }();
+  if (forced) return forced;
+  const KernelEntry *k = find_kernel(s, 1024, false);
+  if (!k) return 512;
+  hipFuncAttributes attr;
+  if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) return 512;
+  return attr.localSizeBytes == 0 ? 1024 : 512;
+}
+
+}  // namespace
+
+nnv_status decode_supported(const PackedShape &s) {
+  return find_kernel(s, 512, false) ? NNV_OK : NNV_ERR_UNSUPPORTED_SHAPE;
+}
+
+int decode_kernel_vgprs(const PackedShape &s) {
+  const KernelEntry *k = find_kernel(s, pick_threads(s), false);
+  if (!k) return 0;
+  hipFuncAttributes attr;
+  if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) return 0;
+  return attr.numRegs;
+}
+
+nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
+                       int lds_limit, LaunchPlan *plan) {
+  if (!find_kernel(s, 512, false)) return NNV_ERR_UNSUPPORTED_SHAPE;
+  const int64_t base_floats = s.hid_floats + s.bias_floats;
+  if (base_floats * 4 > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
+  plan->out_in_lds = ((base_floats + s.out_floats) * 4 <= lds_limit) ? 1 : 0;
+  plan->lds_bytes = static_cast<int32_t>((base_floats + (plan->out_in_lds ? s.out_floats : 0)) * 4);
+  plan->threads = pick_threads(s);
+  const int64_t n_tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
+  const int waves = plan->threads / 64;
+  int64_t blocks = (n_tiles + waves - 1) / waves;
+  if (blocks > num_cus) blocks = num_cus;  // persistent: one workgroup per CU
+  if (blocks < 1) blocks = 1;
+  plan->blocks = static_cast<int32_t>(blocks);
+  return NNV_OK;
+}
+
+nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
+                         const LaunchPlan &plan, bool write_act,
+                         hipStream_t stream) {
+  const int nt = write_act ? 512 : plan.threads;
+  const KernelEntry *k = find_kernel(s, nt, write_act);
+  if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
+  // dynamic LDS above the default cap must be opted into, once per kernel
+  static int lds_set[sizeof(kKernels) / sizeof(kKernels[0])] = {0};
+  const int idx = static_cast<int>(k - kKernels);
+  if (lds_set[idx] < plan.lds_bytes) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k->fn),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            plan.lds_bytes) != hipSuccess)
+      return NNV_ERR_HIP;
+    lds_set[idx] = plan.lds_bytes;
+  }
+  int blocks = plan.blocks;
+  if (write_act) {  // 8 waves per workgroup in the debug variant
+    const int64_t b = (p.n_tiles + 7) / 8;
+    blocks = static_cast<int>(b < plan.blocks ? (b < 1 ? 1 : b) : plan.blocks);
+  }
+  hipLaunchKernelGGL(k->fn, dim3(blocks), dim3(nt), plan.lds_bytes, stream, p);
+  return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+}
+
+}  // namespace nnv

@@ -1,0 +1,234 @@
+"""Device-side decoder object and the ``nnviterbi::mlp_decode`` torch op.
+
+PyTorch is plumbing here (HBM allocations, streams); the arithmetic runs in
+``libnnviterbi_hip.so`` through the C ABI (``include/nnviterbi.h``).
+
+Replaces the reference's ``Session.run`` of
+``tf.argmax(multilayer_perceptron(x, weights, biases), 1)``
+(src/fnn_viterbi.py:494-510,606-610) plus the class->bits and BER/FER loops
+(src/fnn_viterbi.py:639-671).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _cabi
+from ._cabi import NNViterbiError
+
+
+def _as_host_f32(a) -> np.ndarray:
+    if isinstance(a, torch.Tensor):
+        a = a.detach().to("cpu").numpy()
+    return np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+
+
+def _require_cuda():
+    if not torch.cuda.is_available():
+        raise NNViterbiError(
+            "no HIP device visible to PyTorch-ROCm: the decode path runs only "
+            "on MI355X (gfx950); there is no CPU fallback")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class PackedMLP:
+    """A network pre-packed into MFMA fragment order, resident in HBM.
+
+    ``weights[l]`` is ``[n_l, n_{l+1}]`` (the reference's right-multiply
+    layout, src/fnn_viterbi.py:432-456) and ``biases[l]`` is ``[n_{l+1}]``;
+    2..4 dense layers, the last one being the class layer.
+    """
+
+    def __init__(self, weights: Sequence, biases: Sequence, device=None):
+        _require_cuda()
+        self._lib = _cabi.load_library()
+        self.device = torch.device("cuda", torch.cuda.current_device()
+                                   if device is None else torch.device(device).index or 0)
+        Ws = [_as_host_f32(w) for w in weights]
+        bs = [_as_host_f32(b).reshape(-1) for b in biases]
+        if len(Ws) != len(bs) or not (2 <= len(Ws) <= _cabi.NNV_MAX_LAYERS):
+            raise ValueError("need 2..4 dense layers with one bias vector each")
+        dims = [Ws[0].shape[0]]
+        for W, b in zip(Ws, bs):
+            if W.ndim != 2 or W.shape[0] != dims[-1] or b.shape[0] != W.shape[1]:
+                raise ValueError("inconsistent layer shapes")
+            dims.append(W.shape[1])
+        self.dims = dims
+        self.n_input = dims[0]
+        self.n_classes = dims[-1]
+        desc = _cabi.MlpDesc()
+        desc.depth = len(Ws)
+        for i, d in enumerate(dims):
+            desc.dims[i] = d
+        for i, (W, b) in enumerate(zip(Ws, bs)):
+            desc.W_host[i] = W.ctypes.data
+            desc.b_host[i] = b.ctypes.data
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _cabi.check(self._lib.nnv_mlp_prepack(ctypes.byref(desc), ctypes.byref(handle)),
+                        "nnv_mlp_prepack")
+        self._handle = handle
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            self._lib.nnv_mlp_free(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ------------------------------------------------------------
+    def _check_x(self, x: torch.Tensor):
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise TypeError("x must be a CUDA (HIP) tensor")
+        if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != self.n_input:
+            raise ValueError(f"x must be float32 [N, {self.n_input}]")
+        if not x.is_contiguous():
+            raise ValueError("x must be C-contiguous")
+        if x.device != self.device:
+            raise ValueError(f"x is on {x.device}, the network on {self.device}")
+
+    def tile_bits(self) -> int:
+        return max(1, int(np.ceil(np.log2(self.n_classes))))
+
+    # -- the hot path -------------------------------------------------------
+    def decode(self, x: torch.Tensor, labels: Optional[torch.Tensor] = None,
+               tile_bits: Optional[int] = None, want_cls32: bool = True,
+               want_cls64: bool = False, want_bits: bool = False,
+               counters: Optional[torch.Tensor] = None) -> Dict[str, Optional[torch.Tensor]]:
+        """One fused launch: classes (+bits, +error counters) for every row.
+
+        ``counters`` (uint64-as-int64 [4] on the device) is ADDED to; if
+        ``labels`` is given and ``counters`` is None a zeroed one is created.
+        """
+        self._check_x(x)
+        n = x.shape[0]
+        b = self.tile_bits() if tile_bits is None else int(tile_bits)
+        if labels is not None:
+            if labels.dtype != torch.int32 or labels.shape != (n,) or labels.device != x.device:
+                raise ValueError("labels must be int32 [N] on x's device")
+            labels = labels.contiguous()
+            if counters is None:
+                counters = torch.zeros(4, dtype=torch.int64, device=x.device)
+        if counters is not None and (counters.dtype != torch.int64 or counters.numel() != 4):
+            raise ValueError("counters must be int64 [4]")
+        cls32 = torch.empty(n, dtype=torch.int32, device=x.device) if want_cls32 else None
+        cls64 = torch.empty(n, dtype=torch.int64, device=x.device) if want_cls64 else None
+        bits = torch.empty((n, b), dtype=torch.uint8, device=x.device) if want_bits else None
+        with torch.cuda.device(self.device):
+            st = self._lib.nnv_mlp_decode_f32(
+                self._handle, _ptr(x), n, b, _ptr(labels), _ptr(cls32), _ptr(cls64),
+                _ptr(bits), _ptr(counters), _stream_ptr(self.device))
+        _cabi.check(st, "nnv_mlp_decode_f32")
+        return {"cls32": cls32, "cls64": cls64, "bits": bits, "counters": counters}
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """The tanh'd output layer [N, n_classes] (debug / parity; slow)."""
+        self._check_x(x)
+        out = torch.empty((x.shape[0], self.n_classes), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(self.device):
+            st = self._lib.nnv_mlp_forward_f32(self._handle, _ptr(x), x.shape[0], _ptr(out),
+                                               _stream_ptr(self.device))
+        _cabi.check(st, "nnv_mlp_forward_f32")
+        return out
+
+    def decode_timed(self, x: torch.Tensor, labels: Optional[torch.Tensor], cls32: torch.Tensor,
+                     counters: Optional[torch.Tensor], iters: int,
+                     tile_bits: Optional[int] = None) -> float:
+        """``iters`` back-to-back launches between two HIP events recorded on
+        the launch stream; returns elapsed milliseconds."""
+        self._check_x(x)
+        b = self.tile_bits() if tile_bits is None else int(tile_bits)
+        ms = ctypes.c_float(0.0)
+        with torch.cuda.device(self.device):
+            st = self._lib.nnv_mlp_decode_f32_timed(
+                self._handle, _ptr(x), x.shape[0], b, _ptr(labels), _ptr(cls32),
+                _ptr(counters), _stream_ptr(self.device), int(iters), ctypes.byref(ms))
+        _cabi.check(st, "nnv_mlp_decode_f32_timed")
+        return float(ms.value)
+
+    def launch_info(self, n_rows: int) -> Dict[str, int]:
+        info = (ctypes.c_int32 * 8)()
+        with torch.cuda.device(self.device):
+            _cabi.check(self._lib.nnv_mlp_launch_info(self._handle, int(n_rows), info),
+                        "nnv_mlp_launch_info")
+        keys = ("threads", "workgroups", "lds_bytes", "vgprs", "out_layer_in_lds",
+                "rows_per_wave_tile", "depth", "n_classes")
+        return dict(zip(keys, [int(v) for v in info]))
+
+
+def generate_awgn_blocks(code: str, tile_bits: int, n_rows: int, sigma, seed: int,
+                         first_row: int = 0, rows_per_block: int = 1, device=None,
+                         want_labels: bool = True):
+    """On-device synthetic received blocks (C ABI ``nnv_awgn_generate_f32``).
+
+    Returns ``(x [n_rows, 2*tile_bits] float32, labels [n_rows] int32 | None)``.
+    ``sigma`` is a float or a sequence (block i uses sigma[i % len])."""
+    _require_cuda()
+    lib = _cabi.load_library()
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None
+                       else torch.device(device).index or 0)
+    code_id = {"57": _cabi.NNV_CODE_57, "133171": _cabi.NNV_CODE_133171}[str(code)]
+    sig = np.atleast_1d(np.asarray(sigma, dtype=np.float32))
+    x = torch.empty((n_rows, 2 * tile_bits), dtype=torch.float32, device=dev)
+    labels = torch.empty(n_rows, dtype=torch.int32, device=dev) if want_labels else None
+    with torch.cuda.device(dev):
+        st = lib.nnv_awgn_generate_f32(
+            code_id, int(tile_bits), int(n_rows), int(first_row), int(rows_per_block),
+            sig.ctypes.data, int(sig.size), ctypes.c_uint64(int(seed)), _ptr(x), _ptr(labels),
+            _stream_ptr(dev))
+    _cabi.check(st, "nnv_awgn_generate_f32")
+    return x, labels
+
+
+# ---------------------------------------------------------------------------
+# torch custom op:  torch.ops.nnviterbi.mlp_decode
+# ---------------------------------------------------------------------------
+_PACK_CACHE: Dict[tuple, PackedMLP] = {}
+
+
+def _cached_pack(weights: List[torch.Tensor], biases: List[torch.Tensor], device) -> PackedMLP:
+    key = (str(device),) + tuple((t.data_ptr(), t._version, tuple(t.shape))
+                                 for t in list(weights) + list(biases))
+    net = _PACK_CACHE.get(key)
+    if net is None:
+        if len(_PACK_CACHE) > 16:
+            _PACK_CACHE.clear()
+        net = PackedMLP(weights, biases, device=device)
+        _PACK_CACHE[key] = net
+    return net
+
+
+@torch.library.custom_op("nnviterbi::mlp_decode", mutates_args=(), device_types="cuda")
+def mlp_decode(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.Tensor],
+               tile_bits: int, labels: Optional[torch.Tensor] = None
+               ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(cls int64 [N], bits uint8 [N, b], counters int64 [4]) — HIP only."""
+    net = _cached_pack(list(weights), list(biases), x.device)
+    r = net.decode(x, labels=labels, tile_bits=tile_bits, want_cls32=False,
+                   want_cls64=True, want_bits=True)
+    counters = r["counters"]
+    if counters is None:
+        counters = torch.zeros(4, dtype=torch.int64, device=x.device)
+    return r["cls64"], r["bits"], counters
+
+
+@mlp_decode.register_fake
+def _(x, weights, biases, tile_bits, labels=None):
+    n = x.shape[0]
+    return (x.new_empty((n,), dtype=torch.int64), x.new_empty((n, tile_bits), dtype=torch.uint8),
+            x.new_empty((4,), dtype=torch.int64))
