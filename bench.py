@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decoded blocks/s (+ BER) of the feed-forward neural
+Viterbi decode path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+            --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on;
+SURVEY.md section 8d "Config 3"): (133,171) K=7 code, block_len L=64 decoded as
+T=8 independent b=8-bit tiles per block (tiling rule: b = largest divisor of L
+that is <= 10), 10 M blocks = 80 M rows PER GPU (weak scaling), SNR 2 dB,
+3-layer FNN 16 -> 128 -> 64 -> 32 -> 256, tanh on every layer.
+
+One "step" = one pass of the hot path (one fused HIP launch: forward, argmax,
+error counters) over the rank's 10 M resident blocks.  Inputs are generated on
+the device before the timed region (Philox keyed by the global row index, so
+the data do not depend on the number of ranks).  Weights are seeded random
+initialisations of the reference's architecture (no checkpoints ship with the
+reference), so the BER printed is that of an untrained network: it is a parity
+figure (same BER as the CPU oracle on the same rows), not a quality figure.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import nnviterbi_amd  # noqa: E402
+from nnviterbi_amd import distributed as nd  # noqa: E402
+from nnviterbi_amd import fnn_viterbi as fv  # noqa: E402
+from nnviterbi_amd.decoder import PackedMLP, generate_awgn_blocks  # noqa: E402
+
+BLOCK_LEN = 64
+TILE_BITS = 8                      # b: largest divisor of 64 that is <= 10
+ROWS_PER_BLOCK = BLOCK_LEN // TILE_BITS
+SNR_DB = 2.0
+F32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md:42
+SEED = 20240607
+
+
+def algorithmic_work(dims):
+    """per row FLOP = 2*sum(n_i*n_{i+1});
+    bytes = 4*n_in (soft bits in) + 4 (int32 class out)."""
+    flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+    byts = 4 * dims[0] + 4
+    return flop, byts
+
+
+def cpu_baseline(x_dev, labels_dev, Ws, bs, hip_cls, budget_s=12.0):
+    """The oracle's C restatement (oracle/fnn_oracle.c, OpenMP over rows, all
+    host threads) timed on a bounded sample of the same rows; also the parity
+    check of the HIP classes on that sample.  cpu_baseline leg only."""
+    from oracle import fnn_oracle as O
+    threads = O.c_max_threads()
+    probe = 200_000
+    xs = x_dev[:probe].cpu().numpy()
+    t0 = time.perf_counter()
+    O.decode_c(xs, Ws, bs, TILE_BITS, want_bits=False)
+    rate = probe / (time.perf_counter() - t0)
+    n = int(min(x_dev.shape[0], max(probe, rate * budget_s)))
+    n -= n % ROWS_PER_BLOCK
+    xs = x_dev[:n].cpu().numpy()
+    ls = labels_dev[:n].cpu().numpy()
+    t0 = time.perf_counter()
+    ref = O.decode_c(xs, Ws, bs, TILE_BITS, labels=ls, want_bits=False)
+    dt = time.perf_counter() - t0
+    hip = hip_cls[:n].cpu().numpy()
+    mism = int((hip != ref["cls"]).sum())
+    hip_cnt = O.error_counters(hip, ls, TILE_BITS)
+    return {
+        "value": (n / ROWS_PER_BLOCK) / dt, "unit": "blocks/s", "cores": threads, "kind": "port",
+        "sample": f"first {n // ROWS_PER_BLOCK} blocks ({n} rows) of the same workload, "
+                  f"oracle/fnn_oracle.c fp32 fmaf chain + libm tanhf, OpenMP {threads} threads "
+                  f"(the reference's TensorFlow-CPU path is not installable offline)",
+    }, {
+        "rows": n, "class_mismatches": mism,
+        "ber_hip": hip_cnt[0] / hip_cnt[2], "ber_cpu": int(ref["counters"][0]) / int(ref["counters"][2]),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, world = nd.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                  f"torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X (no CPU fallback for the decode path)", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- network: seeded initialisation of the reference architecture ----
+    cfg = fv.DecoderConfig(block_length=TILE_BITS, snr_db=SNR_DB)
+    weights, biases = fv.initialize_weights(cfg, rng=np.random.RandomState(SEED))
+    Ws, bs = fv.weights_as_lists(weights, biases)
+    dims = fv.layer_dims(cfg)
+    net = PackedMLP(Ws, bs, device=dev)
+
+    # ---- this rank's blocks (weak scaling: fixed blocks per GPU) ----------
+    n_blocks = args.blocks_per_gpu
+    n_rows = n_blocks * ROWS_PER_BLOCK
+    first_row = rank * n_rows
+    x, labels = generate_awgn_blocks("133171", TILE_BITS, n_rows, float(cfg.sigma), SEED,
+                                     first_row=first_row, rows_per_block=ROWS_PER_BLOCK, device=dev)
+    cls = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        net.decode_timed(x, labels, cls, counters, 1, tile_bits=TILE_BITS)
+    counters.zero_()
+    torch.cuda.synchronize(dev)
+
+    # ---- timed region: exactly K steps -------------------------------------
+    nd.barrier(dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    kernel_ms = net.decode_timed(x, labels, cls, counters, args.steps, tile_bits=TILE_BITS)
+    torch.cuda.synchronize(dev)
+    nd.barrier(dev)
+    elapsed = time.perf_counter() - t0
+    elapsed = nd.max_over_ranks(elapsed, device=dev)
+    kernel_ms = nd.max_over_ranks(kernel_ms, device=dev)
+
+    total = counters.clone()
+    nd.all_reduce_counters(total)          # the path's one collective (RCCL)
+    ber, fer = nd.rates(total.cpu().numpy())
+
+    if rank == 0:
+        flop_row, bytes_row = algorithmic_work(dims)
+        launch_s = kernel_ms / 1e3 / args.steps
+        achieved = flop_row * n_rows / launch_s / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("rows_per_launch") == n_rows:
+                traffic = tj.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "decoded blocks/sec, (133,171) block_len=64 @ SNR 2 dB",
+            "value": world * n_blocks * args.steps / elapsed,
+            "unit": "blocks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: (133,171) K=7, block_len=64 as 8 tiles of b=8, "
+                            "10M blocks/GPU @ SNR 2 dB, 3-layer FNN 16-128-64-32-256",
+                "blocks_per_gpu": n_blocks, "rows_per_block": ROWS_PER_BLOCK,
+                "net": dims, "weights": "seeded random init (untrained)",
+                "parallelism": f"block-shard x{world}, counters all-reduce only",
+            },
+            "ber": ber, "fer": fer,
+            "roofline": {
+                "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "kernel_ms_per_launch": launch_s * 1e3,
+                "algorithmic_flop_per_launch": flop_row * n_rows,
+                "algorithmic_bytes_per_launch": bytes_row * n_rows,
+                "hbm_frac_of_8TBs": bytes_row * n_rows / launch_s / 8.0e12,
+            },
+            "launch": net.launch_info(n_rows),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, parity = cpu_baseline(x, labels, Ws, bs, cls)
+            out["cpu_baseline"] = base
+            out["parity_sample"] = parity
+        print(json.dumps(out))
+    nd.barrier(dev)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+"""Block sharding over GPUs and the one collective of this path.
+
+The reference has no distributed code (single process).
+Rows of the decoder input are independent (src/fnn_viterbi.py:494-510 has no
+cross-row op), so codeword blocks shard embarrassingly: each rank owns a
+contiguous range of GLOBAL block indices, generates/reads exactly those blocks
+(the on-device generator is keyed by the global row index, so the data do not
+depend on the number of ranks), and the only exchange is one SUM all-reduce of
+the error counters ``{bit_errors, frame_errors, total_bits, total_frames}``
+(x n_snr bins for a mixed-SNR sweep): tens of bytes over RCCL/xGMI.
+Decoded bits stay on the GPU that produced them.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def block_shard(n_blocks: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous split, remainder to the low ranks -> (first_block, count)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, rem = divmod(int(n_blocks), int(world_size))
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Join the process group described by torchrun's environment.
+
+    Returns (rank, local_rank, world_size); a no-op for a single process.
+    backend: "nccl" (= RCCL on ROCm) when CUDA/HIP is available, else "gloo".
+    """
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def all_reduce_counters(counters: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place SUM of an int64 counter tensor over all ranks (any shape)."""
+    if counters.dtype != torch.int64:
+        raise ValueError("counters must be int64")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
+    return counters
+
+
+def max_over_ranks(value: float, device=None, group=None) -> float:
+    """MAX all-reduce of a python float (timing)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64,
+                     device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def barrier(device=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if device is not None and torch.device(device).type == "cuda":
+            dist.barrier(device_ids=[torch.device(device).index])
+        else:
+            dist.barrier()
+
+
+def rates(counters) -> Tuple[float, float]:
+    """(BER, FER) from {bit_errors, frame_errors, total_bits, total_frames}
+    (src/fnn_viterbi.py:640,671)."""
+    c = [int(v) for v in counters]
+    ber = c[0] / c[2] if c[2] else float("nan")
+    fer = c[1] / c[3] if c[3] else float("nan")
+    return ber, fer

@@ -1,0 +1,78 @@
+"""Training loop of the feed-forward decoder.
+
+Restates the optimisation the reference builds in TensorFlow
+(src/fnn_viterbi.py:547-603; src/fnn_viterbi_mixed_snr.py:722-779):
+
+  * loss = mean softmax cross-entropy taken ON THE TANH OUTPUTS (the network's
+    last op is tanh, and that tensor is passed as ``logits``)
+    + beta * (l2(h1) + l2(h2) + l2(h3)), with tf.nn.l2_loss(w) = sum(w^2)/2;
+    the output layer's weights are not regularised;
+  * Adam, learning rate from the config, TF defaults otherwise;
+  * contiguous, unshuffled, class-major mini-batches; the remainder that does
+    not fill a batch is dropped (``int(num_training_samples / batch_size)``);
+  * optional dropout after each hidden tanh (mixed_snr:596-627), evaluation
+    always without dropout (:715-720).
+
+Training is not the hot path of this project: it is plain PyTorch autograd
+(on the GPU when there is one).  Decoding with the trained weights goes
+through the HIP kernel.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+
+def _device():
+    return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def train_network(config, training_set: np.ndarray, training_labels: np.ndarray,
+                  weights: Dict[str, np.ndarray], biases: Dict[str, np.ndarray],
+                  use_dropout: bool = False, keep_prob: float = 0.5,
+                  verbose: bool = True) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
+    """Returns trained copies of (weights, biases), keyed like the inputs."""
+    dev = _device()
+    w_keys = [k for k in ("h1", "h2", "h3") if k in weights] + ["out"]
+    b_keys = [k for k in ("b1", "b2", "b3") if k in biases] + ["out"]
+    W = [torch.tensor(np.asarray(weights[k]), dtype=torch.float32, device=dev, requires_grad=True)
+         for k in w_keys]
+    B = [torch.tensor(np.asarray(biases[k]), dtype=torch.float32, device=dev, requires_grad=True)
+         for k in b_keys]
+    x_all = torch.as_tensor(np.asarray(training_set), dtype=torch.float32, device=dev)
+    y_all = torch.as_tensor(np.asarray(training_labels), dtype=torch.float32, device=dev)
+    opt = torch.optim.Adam(W + B, lr=config.learning_rate, betas=(0.9, 0.999), eps=1e-8)
+    bs = int(config.batch_size)
+    total_batch = int(config.num_training_samples / bs)
+    beta = float(config.beta_regularization)
+    n_hidden = len(W) - 1
+
+    def model(xb, train: bool):
+        h = xb
+        for i in range(n_hidden):
+            h = torch.tanh(h @ W[i] + B[i])
+            if train and use_dropout:
+                h = torch.nn.functional.dropout(h, p=1.0 - keep_prob, training=True)
+        return torch.tanh(h @ W[-1] + B[-1])
+
+    for epoch in range(int(config.training_epochs)):
+        avg_cost = torch.zeros((), device=dev)
+        for i in range(total_batch):
+            xb = x_all[i * bs:(i + 1) * bs]
+            yb = y_all[i * bs:(i + 1) * bs]
+            pred = model(xb, True)
+            ce = -(yb * torch.log_softmax(pred, dim=1)).sum(dim=1).mean()
+            reg = sum(0.5 * (w * w).sum() for w in W[:n_hidden])
+            cost = ce + beta * reg
+            opt.zero_grad(set_to_none=True)
+            cost.backward()
+            opt.step()
+            avg_cost += cost.detach() / max(total_batch, 1)
+        if verbose and epoch % int(getattr(config, "display_step", 1)) == 0:
+            print(f"Epoch: {epoch + 1:04d} | cost = {float(avg_cost):.9f}")
+
+    new_w = {k: w.detach().cpu().numpy().copy() for k, w in zip(w_keys, W)}
+    new_b = {k: b.detach().cpu().numpy().copy() for k, b in zip(b_keys, B)}
+    return new_w, new_b

@@ -1,0 +1,399 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the
+oracle on the same seeded inputs, against the committed golden fixtures, and
+at BASELINE.json's full size through size-independent properties.
+
+Stated tolerance (DESIGN.md "Parity"): the tanh'd outputs are within 1e-5
+(absolute) of the float64 restatement, and a decoded class may differ from the
+float64 argmax only on rows whose float64 top-2 margin is below 1e-5; integer
+outputs derived from the class (bits, error counters) are bit-exact functions
+of it.  Run with:  python -m pytest tests -m gpu
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import nnviterbi_amd  # noqa: F401
+from nnviterbi_amd import fnn_viterbi as fv
+from nnviterbi_amd import fnn_viterbi_mixed_snr as mx
+from nnviterbi_amd.decoder import PackedMLP, generate_awgn_blocks
+from oracle import awgn_model
+from oracle import fnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _net(dims, seed, bias_scale=0.1):
+    rng = np.random.RandomState(seed)
+    Ws = [fv.truncated_normal((dims[i], dims[i + 1]), np.sqrt(2.0 / dims[i]), rng)
+          for i in range(len(dims) - 1)]
+    bs = [(rng.randn(dims[i + 1]) * bias_scale).astype(np.float32) for i in range(len(dims) - 1)]
+    return Ws, bs
+
+
+def _assert_parity(cls, act, x, Ws, bs, b):
+    c64, _, o64 = O.decode(x, Ws, bs, b, np.float64)
+    if act is not None:
+        assert np.abs(act - o64).max() < TOL
+    bad = cls != c64
+    if bad.any():
+        assert O.top2_margin(o64)[bad].max() < TOL, "class differs on a row that is not a near-tie"
+    return int(bad.sum())
+
+
+def _hip_decode(net, x, labels=None, b=None, **kw):
+    xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    ld = None if labels is None else torch.from_numpy(labels.astype(np.int32)).cuda()
+    r = net.decode(xd, labels=ld, tile_bits=b, want_cls64=True, want_bits=True, **kw)
+    torch.cuda.synchronize()
+    return {k: (None if v is None else v.cpu().numpy()) for k, v in r.items()}
+
+
+# ------------------------------------------------------------------ fixtures
+@pytest.mark.parametrize("name,depth,b", [("b8_l3", 4, 8), ("b7_l3", 4, 7),
+                                          ("b10_l2", 3, 10), ("b3_l3", 4, 3)])
+def test_golden_forward_fixtures(cuda_device, forward_golden, name, depth, b):
+    fg = forward_golden
+    Ws = [fg[f"{name}_W{i}"] for i in range(depth)]
+    bs = [fg[f"{name}_b{i}"] for i in range(depth)]
+    x, labels = fg[f"{name}_x"], fg[f"{name}_labels"]
+    net = PackedMLP(Ws, bs)
+    r = _hip_decode(net, x, labels, b)
+    act = net.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    bad = r["cls32"] != fg[f"{name}_cls"]
+    assert not bad.any() or fg[f"{name}_margin"][bad].max() < TOL
+    assert np.abs(act[:16] - fg[f"{name}_out_head"]).max() < TOL
+    _assert_parity(r["cls32"], act, x, Ws, bs, b)
+    assert np.array_equal(r["cls64"], r["cls32"].astype(np.int64))
+    assert np.array_equal(r["bits"], O.class_to_bits(r["cls32"], b))
+    assert np.array_equal(r["counters"], O.error_counters(r["cls32"], labels, b))
+    if not bad.any():
+        assert np.array_equal(r["counters"], fg[f"{name}_counters"])
+    net.close()
+
+
+# ------------------------------------------------------------------ shapes, tails, edge cases
+SHAPES = [
+    ([16, 128, 64, 32, 256], 8),     # BASELINE configs[2] row shape
+    ([14, 128, 64, 32, 128], 7),     # reference default (scalar x loads: 56-byte rows)
+    ([20, 128, 64, 32, 1024], 10),   # configs[0] row shape (output layer streamed from L2)
+    ([20, 128, 64, 1024], 10),       # configs[1] row shape (2-layer)
+    ([12, 128, 64, 32, 64], 6),
+    ([6, 128, 64, 32, 8], 3),        # fewer classes than one 32-wide tile
+    ([16, 128, 256], 8),             # 1 hidden layer
+    ([16, 100, 50, 20, 256], 8),     # hidden widths that are not multiples of 32
+    ([24, 128, 64, 32, 4096], 12),   # widest supported input, 4096 classes
+]
+
+
+@pytest.mark.parametrize("dims,b", SHAPES)
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 4099])
+def test_decode_matches_oracle(cuda_device, dims, b, n):
+    Ws, bs = _net(dims, seed=b * 100 + len(dims))
+    rng = np.random.RandomState(n)
+    x = (rng.randn(n, dims[0]) * 1.2).astype(np.float32)
+    labels = rng.randint(0, dims[-1], size=n).astype(np.int32)
+    net = PackedMLP(Ws, bs)
+    r = _hip_decode(net, x, labels, b)
+    act = net.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    _assert_parity(r["cls32"], act, x, Ws, bs, b)
+    ref = O.decode_c(x, Ws, bs, b, labels=labels)
+    assert (r["cls32"] != ref["cls"]).sum() <= max(1, n // 1000)
+    assert np.array_equal(r["bits"], O.class_to_bits(r["cls32"], b))
+    assert np.array_equal(r["counters"], O.error_counters(r["cls32"], labels, b))
+    net.close()
+
+
+def test_large_random_batch_flip_rate(cuda_device):
+    """1e6 rows, config-3 row shape: report/assert the near-tie flip rate."""
+    dims, b, n = [16, 128, 64, 32, 256], 8, 1_000_000
+    Ws, bs = _net(dims, seed=5, bias_scale=0.0)
+    rng = np.random.RandomState(1)
+    x = rng.randn(n, 16).astype(np.float32)
+    net = PackedMLP(Ws, bs)
+    r = _hip_decode(net, x, None, b)
+    ref = O.decode_c(x, Ws, bs, b, want_bits=False)
+    diff = np.flatnonzero(r["cls32"] != ref["cls"])
+    assert len(diff) <= 20                       # fp32 summation-order ties: ~1e-6 of rows
+    if len(diff):
+        _assert_parity(r["cls32"][diff], None, x[diff], Ws, bs, b)
+    net.close()
+
+
+def test_empty_input_is_a_noop(cuda_device):
+    Ws, bs = _net([16, 128, 64, 32, 256], 1)
+    net = PackedMLP(Ws, bs)
+    x = torch.empty((0, 16), dtype=torch.float32, device="cuda")
+    lab = torch.empty((0,), dtype=torch.int32, device="cuda")
+    r = net.decode(x, labels=lab, tile_bits=8, want_bits=True)
+    assert r["cls32"].numel() == 0 and r["bits"].shape == (0, 8)
+    assert r["counters"].cpu().tolist() == [0, 0, 0, 0]
+    assert net.forward(x).shape == (0, 256)
+    net.close()
+
+
+def test_counters_accumulate_across_launches(cuda_device):
+    Ws, bs = _net([16, 128, 64, 32, 256], 2)
+    net = PackedMLP(Ws, bs)
+    rng = np.random.RandomState(0)
+    x = torch.from_numpy(rng.randn(1000, 16).astype(np.float32)).cuda()
+    lab = torch.from_numpy(rng.randint(0, 256, 1000).astype(np.int32)).cuda()
+    one = net.decode(x, labels=lab, tile_bits=8)["counters"].cpu().numpy()
+    acc = torch.zeros(4, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        net.decode(x, labels=lab, tile_bits=8, counters=acc)
+    assert np.array_equal(acc.cpu().numpy(), 3 * one)
+    net.close()
+
+
+def test_misaligned_and_strided_inputs(cuda_device):
+    dims, b, n = [16, 128, 64, 32, 256], 8, 777
+    Ws, bs = _net(dims, 3)
+    net = PackedMLP(Ws, bs)
+    rng = np.random.RandomState(2)
+    x = rng.randn(n, 16).astype(np.float32)
+    base = torch.zeros(n * 16 + 3, dtype=torch.float32, device="cuda")
+    view = base[3:].view(n, 16)                     # 12-byte offset: vector loads are illegal
+    view.copy_(torch.from_numpy(x))
+    assert view.data_ptr() % 16 != 0
+    a = net.decode(view, tile_bits=8)["cls32"].cpu().numpy()
+    c = net.decode(torch.from_numpy(x).cuda(), tile_bits=8)["cls32"].cpu().numpy()
+    assert np.array_equal(a, c)
+    with pytest.raises(ValueError):
+        net.decode(torch.from_numpy(x).cuda()[:, ::2], tile_bits=8)      # wrong width
+    with pytest.raises(ValueError):
+        net.decode(torch.from_numpy(x).cuda().t().contiguous().t(), tile_bits=8)  # not contiguous
+    with pytest.raises(TypeError):
+        net.decode(torch.from_numpy(x), tile_bits=8)                      # host tensor
+    net.close()
+
+
+def _tanh_probe_net(z):
+    """Network whose output layer is tanh(z) for chosen z: zero weights, z as the
+    output bias.  32 values per probe."""
+    Ws = [np.zeros((2, 128), np.float32), np.zeros((128, 32), np.float32)]
+    bs = [np.zeros(128, np.float32), np.asarray(z, np.float32)]
+    return PackedMLP(Ws, bs)
+
+
+def test_tanh_accuracy_and_limits(cuda_device):
+    x = torch.zeros((1, 2), dtype=torch.float32, device="cuda")
+    worst = 0.0
+    for lo, hi in ((-12, 12), (-1, 1), (-0.01, 0.01), (4, 10)):
+        for k in range(4):
+            z = np.linspace(lo, hi, 32 * 4, dtype=np.float32)[k::4]
+            net = _tanh_probe_net(z)
+            out = net.forward(x).cpu().numpy()[0]
+            worst = max(worst, np.abs(out - np.tanh(z.astype(np.float64))).max())
+            net.close()
+    assert worst < 3e-7
+    z = np.array([30, -30, 100, -100, 1e30, -1e30, np.inf, -np.inf] + [0.0] * 24, np.float32)
+    net = _tanh_probe_net(z)
+    out = net.forward(x).cpu().numpy()[0]
+    assert out[:8].tolist() == [1, -1, 1, -1, 1, -1, 1, -1] and not out[8:].any()
+    net.close()
+
+
+def test_saturated_outputs_resolve_to_the_first_maximum(cuda_device):
+    """tanh saturates to exactly 1.0f for several classes: tf.argmax / np.argmax
+    pick the first (src/fnn_viterbi.py:607,635)."""
+    x = torch.zeros((40, 16), dtype=torch.float32, device="cuda")
+    Ws = [np.zeros((16, 128), np.float32), np.zeros((128, 64), np.float32),
+          np.zeros((64, 32), np.float32), np.zeros((32, 256), np.float32)]
+    for hot, want in (([5, 200], 5), (list(range(256)), 0), ([255], 255), ([36, 4, 68], 4),
+                      ([32 + 4], 36)):
+        bo = np.full(256, -3.0, np.float32)
+        bo[hot] = 30.0
+        net = PackedMLP(Ws, [np.zeros(128, np.float32), np.zeros(64, np.float32),
+                             np.zeros(32, np.float32), bo])
+        assert set(net.decode(x, tile_bits=8)["cls32"].cpu().tolist()) == {want}
+        ref = O.decode_c(np.zeros((2, 16), np.float32), Ws, [np.zeros(128, np.float32),
+                         np.zeros(64, np.float32), np.zeros(32, np.float32), bo], 8)
+        assert ref["cls"].tolist() == [want, want]
+        net.close()
+
+
+def test_unsupported_network_fails_loudly(cuda_device):
+    with pytest.raises(nnviterbi_amd.NNViterbiError):
+        PackedMLP(*_net([16, 512, 256], 0))          # no kernel instantiation for this width
+    with pytest.raises(ValueError):
+        PackedMLP([np.zeros((16, 256), np.float32)], [np.zeros(256, np.float32)])  # depth 1
+
+
+# ------------------------------------------------------------------ generator (K3)
+@pytest.mark.parametrize("code,b", [("133171", 8), ("133171", 7), ("57", 10), ("57", 5)])
+def test_generator_matches_the_numpy_model(cuda_device, code, b):
+    n, seed, sig = 5000, 1234567890123, [0.5616748812614791, 0.4461542169214011, 0.7]
+    x, lab = generate_awgn_blocks(code, b, n, sig, seed, first_row=77, rows_per_block=4)
+    mx_, ml = awgn_model.generate(code, b, n, sig, seed, first_row=77, rows_per_block=4)
+    assert np.array_equal(lab.cpu().numpy(), ml)                 # Philox + encoder: bit exact
+    assert np.abs(x.cpu().numpy() - mx_).max() < 1e-5            # float32 Box-Muller vs float64
+    x0, _ = generate_awgn_blocks(code, b, n, 0.0, seed, first_row=77, rows_per_block=4)
+    m0, _ = awgn_model.generate(code, b, n, 0.0, seed, first_row=77, rows_per_block=4)
+    assert np.array_equal(x0.cpu().numpy(), m0)                  # noiseless: the codewords themselves
+
+
+def test_generator_is_independent_of_sharding_and_rejects_short_tiles(cuda_device):
+    x, lab = generate_awgn_blocks("133171", 8, 4096, 0.5, 9, rows_per_block=8)
+    xa, la = generate_awgn_blocks("133171", 8, 1000, 0.5, 9, first_row=0, rows_per_block=8)
+    xb, lb = generate_awgn_blocks("133171", 8, 3096, 0.5, 9, first_row=1000, rows_per_block=8)
+    assert torch.equal(torch.cat([xa, xb]), x) and torch.equal(torch.cat([la, lb]), lab)
+    with pytest.raises(nnviterbi_amd.NNViterbiError):
+        generate_awgn_blocks("133171", 5, 10, 0.5, 0)            # encode_133171 needs >= 6 bits
+    with pytest.raises(nnviterbi_amd.NNViterbiError):
+        generate_awgn_blocks("57", 1, 10, 0.5, 0)
+
+
+# ------------------------------------------------------------------ full size (BASELINE configs[2])
+def matched_filter_network(b, code):
+    """A hand-built network of the reference's architecture that decodes
+    noiseless codewords exactly: the hidden layers pass the 2b soft bits through
+    (tanh is ~linear for small arguments), the class layer correlates with every
+    codeword.  encode -> decode is then the identity: a size-independent property."""
+    cb = fv.generate_class_bits(b)
+    enc = fv.encode_133171_batch(cb) if code == "133171" else fv.encode_57_batch(cb)
+    sym = np.where(enc == 1, 1.0, -1.0).astype(np.float32)        # [C, 2b]
+    n = 2 * b
+    dims = [n, 128, 64, 32, 2 ** b]
+    Ws = [np.zeros((dims[i], dims[i + 1]), np.float32) for i in range(4)]
+    Ws[0][np.arange(n), np.arange(n)] = 0.05
+    Ws[1][np.arange(n), np.arange(n)] = 1.0
+    Ws[2][np.arange(n), np.arange(n)] = 1.0
+    Ws[3][:n, :] = sym.T * 2.0
+    return Ws, [np.zeros(d, np.float32) for d in dims[1:]]
+
+
+def test_full_size_round_trip_and_counter_identities(cuda_device):
+    """10 M blocks = 80 M rows (the benchmark's per-GPU workload)."""
+    b, rows_per_block, n_blocks = 8, 8, 10_000_000
+    n = n_blocks * rows_per_block
+    Ws, bs = matched_filter_network(b, "133171")
+    net = PackedMLP(Ws, bs)
+    # (1) encode -> noiseless channel -> decode == identity, for every row
+    x, lab = generate_awgn_blocks("133171", b, n, 0.0, seed=42, rows_per_block=rows_per_block)
+    r = net.decode(x, labels=lab, tile_bits=b)
+    assert torch.equal(r["cls32"], lab)
+    assert r["counters"].cpu().tolist() == [0, 0, n * b, n]
+    # (2) at 2 dB the same network is a maximum-likelihood decoder of each tile:
+    #     counters are exact integer functions of (classes, labels), recomputed with torch
+    del x
+    x, lab = generate_awgn_blocks("133171", b, n, 0.5616748812614791, seed=43,
+                                  rows_per_block=rows_per_block)
+    r = net.decode(x, labels=lab, tile_bits=b)
+    cls = r["cls32"]
+    diff = torch.bitwise_xor(cls, lab)
+    pop = torch.zeros_like(diff)
+    for s in range(b):
+        pop += (diff >> s) & 1
+    want = [int(pop.sum()), int((diff != 0).sum()), n * b, n]
+    assert r["counters"].cpu().tolist() == want
+    ber = want[0] / want[2]
+    assert 1e-4 < ber < 0.05                        # ML decoding of unterminated 8-bit tiles at 2 dB
+    # (3) determinism and (4) row-permutation equivariance on a slice
+    again = net.decode(x, tile_bits=b)["cls32"]
+    assert torch.equal(again, cls)
+    perm = torch.randperm(1 << 20, device="cuda")
+    sub = x[: 1 << 20][perm].contiguous()
+    assert torch.equal(net.decode(sub, tile_bits=b)["cls32"], cls[: 1 << 20][perm])
+    # (5) a bounded sample against the oracle
+    m = 200_000
+    ref = O.decode_c(x[:m].cpu().numpy(), Ws, bs, b, labels=lab[:m].cpu().numpy(), want_bits=False)
+    assert (cls[:m].cpu().numpy() != ref["cls"]).sum() <= 2
+    net.close()
+
+
+# ------------------------------------------------------------------ reference-shaped API on the GPU
+def test_reference_api_predict_and_metrics(cuda_device, golden):
+    g, _ = golden
+    cfg = fv.DecoderConfig(block_length=7, samples_per_class_train=2, samples_per_class_test=4)
+    weights, biases = fv.initialize_weights(cfg, rng=np.random.RandomState(8))
+    test_set = g["ds7_test"]
+    labels_idx = g["ds7_test_labels_idx"]
+    preds, counters = fv.predict(test_set, weights, biases, labels=labels_idx, tile_bits=7)
+    assert preds.dtype == np.int64
+    Ws, bs = fv.weights_as_lists(weights, biases)
+    _assert_parity(preds, fv.multilayer_perceptron(test_set, weights, biases), test_set, Ws, bs, 7)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        fv.calculate_error(fv.create_one_hot_labels(labels_idx, 128), preds,
+                           fv.generate_class_bits(7), cfg)
+    lines = buf.getvalue().splitlines()
+    assert lines[3] == f"Total Bit Errors: {counters[0]}/{counters[2]}"
+    assert mx.calculate_ber(preds, labels_idx, 7) == counters[0] / counters[2]
+    assert mx.calculate_accuracy(preds, labels_idx) == 1 - counters[1] / counters[3]
+
+
+def test_create_model_graph_restore_and_run_graph(cuda_device, tmp_path, golden):
+    g, meta = golden
+    kw = dict(meta["mix"]["kwargs"])
+    kw["snr_db_range"] = tuple(kw["snr_db_range"])
+    cfg = mx.MixedSNRDecoderConfig(**kw)
+    weights, biases = mx.initialize_weights(cfg, rng=np.random.RandomState(3))
+    path = str(tmp_path / "mixed_snr_model")
+    mx.save_model(path, weights, biases)
+    np.random.seed(meta["mix"]["seed"])
+    tr, te, trl, rl, rs, cb = mx.get_dataset(cfg)
+    tel = mx.create_one_hot_labels(mx.get_dataset.last_test_labels, cfg.n_classes)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        model = mx.create_model_graph(cfg, tr, trl, te, tel, rs, rl, train_mode=False,
+                                      model_load_path=path)
+    out = buf.getvalue().splitlines()
+    assert out[0] == f"Model loaded from {path}"
+    assert out[1].startswith("Test Set Accuracy: ") and out[2].startswith("Test Set BER: ")
+    labels_idx = np.argmax(tel, axis=1)
+    assert model.ber == mx.calculate_ber(model.predictions, labels_idx, cfg.block_length)
+    assert model.accuracy == mx.calculate_accuracy(model.predictions, labels_idx)
+    Ws, bs = mx.weights_as_lists(weights, biases)
+    _assert_parity(model.predictions, None, te, Ws, bs, cfg.block_length)
+    with contextlib.redirect_stdout(io.StringIO()):
+        again = mx.run_graph(model)                  # README: model = create_model_graph(); run_graph(model)
+    assert np.array_equal(again, model.predictions)
+    cfg.use_random_test_set = True
+    with contextlib.redirect_stdout(io.StringIO()) as b2:
+        m2 = mx.create_model_graph(cfg, tr, trl, te, tel, rs, rl, train_mode=False,
+                                   model_load_path=path)
+    assert b2.getvalue().splitlines()[1].startswith("Random Test Set Accuracy: ")
+    _assert_parity(m2.predictions, None, rs.astype(np.float32), Ws, bs, cfg.block_length)
+
+
+def test_run_network_trains_and_decodes(cuda_device):
+    cfg = fv.DecoderConfig(block_length=6, samples_per_class_train=40, samples_per_class_test=20,
+                           training_epochs=30, batch_size=64, learning_rate=0.003, snr_db=6.0)
+    np.random.seed(0)
+    tr, trl, te, tel, cb = fv.train_test_dataset(cfg)
+    np.random.seed(1)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        preds = fv.run_network(cfg, tr, trl, te, tel)
+        fv.calculate_error(tel, preds, cb, cfg)
+    text = buf.getvalue()
+    assert "Epoch: 0001 | cost = " in text and "Optimization Finished!" in text
+    acc = float(text.split("Accuracy: ")[1].split()[0])
+    assert acc > 0.5                                  # a 64-class problem: chance is 0.016
+    weights, biases = fv.run_network.last_model
+    Ws, bs = fv.weights_as_lists(weights, biases)
+    _assert_parity(preds, None, te, Ws, bs, 6)
+
+
+def test_torch_custom_op(cuda_device):
+    dims, b, n = [16, 128, 64, 32, 256], 8, 3000
+    Ws, bs = _net(dims, 9)
+    rng = np.random.RandomState(4)
+    x = rng.randn(n, 16).astype(np.float32)
+    labels = rng.randint(0, 256, n).astype(np.int32)
+    tw = [torch.from_numpy(w).cuda() for w in Ws]
+    tb = [torch.from_numpy(v).cuda() for v in bs]
+    cls, bits, counters = torch.ops.nnviterbi.mlp_decode(
+        torch.from_numpy(x).cuda(), tw, tb, b, torch.from_numpy(labels).cuda())
+    assert cls.dtype == torch.int64 and bits.dtype == torch.uint8 and counters.shape == (4,)
+    c = cls.cpu().numpy()
+    _assert_parity(c, None, x, Ws, bs, b)
+    assert np.array_equal(bits.cpu().numpy(), O.class_to_bits(c, b))
+    assert np.array_equal(counters.cpu().numpy(), O.error_counters(c, labels, b))
+    with pytest.raises(Exception):
+        torch.ops.nnviterbi.mlp_decode(torch.from_numpy(x), tw, tb, b, None)   # CPU tensor: no kernel

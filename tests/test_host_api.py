@@ -1,0 +1,256 @@
+"""The package's host-side mirror of the reference API (numpy half) against
+golden vectors produced by the reference itself, plus the assertions of the
+reference's own unit tests that hold for the shipped code (tests/test_encoders.py,
+tests/test_utilities.py; those files cannot be collected as shipped).
+CPU only: nothing here calls the HIP path."""
+import contextlib
+import io
+import random
+
+import numpy as np
+import pytest
+
+import nnviterbi_amd  # noqa: F401
+from nnviterbi_amd import fnn_viterbi as fv
+from nnviterbi_amd import fnn_viterbi_mixed_snr as mx
+from oracle import fnn_oracle as O
+
+
+def _stdout(fn, *a):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        fn(*a)
+    return buf.getvalue()
+
+
+# ---------------------------------------------------------------- encoders
+def test_encoders_match_reference_vectors(golden):
+    g, meta = golden
+    for i in range(meta["n_enc_inputs"]):
+        bits = g[f"enc_in_{i}"]
+        out = fv.encode_57(bits)
+        assert out.dtype == np.int32 and np.array_equal(out, g[f"enc57_out_{i}"])
+        assert np.array_equal(mx.encode_57(bits), out)
+        if len(bits) >= 6:
+            out = fv.encode_133171(bits)
+            assert out.dtype == np.int32 and np.array_equal(out, g[f"enc133171_out_{i}"])
+
+
+def test_batch_encoders_equal_loop_encoders(golden):
+    g, _ = golden
+    for b in (3, 7, 8, 10):
+        cb = g[f"class_bits_{b}"]
+        assert np.array_equal(fv.encode_57_batch(cb), g[f"codebook57_{b}"])
+        if b >= 6:
+            assert np.array_equal(fv.encode_133171_batch(cb), g[f"codebook133171_{b}"])
+    rng = np.random.RandomState(3)
+    u = rng.randint(0, 2, size=(5, 40))
+    assert np.array_equal(fv.encode_133171_batch(u), np.stack([O.encode_133171(r) for r in u]))
+    assert np.array_equal(fv.encode_57_batch(u), np.stack([O.encode_57(r) for r in u]))
+
+
+def test_encoder_error_behaviour():
+    with pytest.raises(IndexError):
+        fv.encode_133171(np.array([1]))            # reference tests/test_encoders.py:204-209 expects
+    with pytest.raises(IndexError):                # a result; the shipped code raises
+        fv.encode_133171(np.zeros(5, dtype=np.int32))
+    with pytest.raises(IndexError):
+        fv.encode_57(np.array([1]))
+
+
+def test_reference_encoder_unit_test_assertions():
+    # tests/test_encoders.py:44-106 (lengths, zeros, binary, determinism) and :169-182 (linearity)
+    assert len(fv.encode_57(np.array([1, 0, 1, 0, 1]))) == 10
+    assert np.all(fv.encode_57(np.zeros(5, dtype=np.int32)) == 0)
+    assert fv.encode_57(np.array([1, 0, 0, 0, 0]))[0] == 1
+    assert len(fv.encode_133171(np.array([1, 0, 1, 0, 1, 1, 0]))) == 14
+    assert np.all(fv.encode_133171(np.zeros(10, dtype=np.int32)) == 0)
+    e = fv.encode_133171(np.ones(10, dtype=np.int32))
+    assert len(e) == 20 and np.all((e == 0) | (e == 1))
+    rng = np.random.RandomState(0)
+    a, b = rng.randint(0, 2, 20), rng.randint(0, 2, 20)
+    assert np.array_equal(fv.encode_133171((a + b) % 2),
+                          (fv.encode_133171(a) + fv.encode_133171(b)) % 2)
+    s = fv.generate_info_sequence(100)
+    assert len(s) == 100 and s.dtype == np.int32 and np.all((s == 0) | (s == 1))
+
+
+def test_generate_info_sequence_follows_python_random(golden):
+    g, _ = golden
+    random.seed(5)
+    assert np.array_equal(fv.generate_info_sequence(16), g["info_seq_seed5"])
+
+
+# ---------------------------------------------------------------- channel / dataset
+def test_modulate_awgn(golden):
+    g, _ = golden
+    np.random.seed(7)
+    out = fv.modulate_awgn(g["awgn_in"], 0.5616748812614791)
+    assert out.dtype == np.float64 and np.array_equal(out, g["awgn_out_seed7"])
+    assert g["awgn_in"].tolist() == [0, 1, 1, 0, 1, 0, 0, 1]      # input not modified
+
+
+def test_config_fields(golden):
+    _, meta = golden
+    c = fv.DecoderConfig()
+    for k, v in meta["default_config"].items():
+        assert getattr(c, k) == v, k
+    for db, s in meta["sigma_by_snr_db"].items():
+        assert fv.DecoderConfig(snr_db=float(db)).sigma == s
+    m = mx.MixedSNRDecoderConfig()
+    md = meta["mixed_default_config"]
+    assert m.snr_db_vec.tolist() == md["snr_db_vec"]
+    assert np.array_equal(m.sigma_vec, np.array(md["sigma_vec"]))
+    for k in ("samples_per_snr", "random_test_length", "num_training_samples",
+              "num_test_samples", "n_input", "n_classes"):
+        assert getattr(m, k) == md[k], k
+
+
+def test_train_test_dataset_is_bit_identical(golden):
+    g, meta = golden
+    cfg = fv.DecoderConfig(block_length=7, samples_per_class_train=2, samples_per_class_test=4)
+    np.random.seed(meta["ds7"]["seed"])
+    tr, trl, te, tel, cb = fv.train_test_dataset(cfg)
+    assert tr.dtype == np.float32 and te.dtype == np.float32 and trl.dtype == np.float32
+    assert list(tr.shape) == meta["ds7"]["train_shape"] and list(tel.shape) == meta["ds7"]["labels_shape"]
+    assert te.flags["C_CONTIGUOUS"]
+    assert np.array_equal(tr, g["ds7_train"]) and np.array_equal(te, g["ds7_test"])
+    assert np.array_equal(np.argmax(trl, 1), g["ds7_train_labels_idx"])
+    assert np.array_equal(np.argmax(tel, 1), g["ds7_test_labels_idx"])
+    assert np.array_equal(cb, g["class_bits_7"])
+
+
+def test_get_dataset_is_bit_identical(golden):
+    g, meta = golden
+    kw = dict(meta["mix"]["kwargs"])
+    kw["snr_db_range"] = tuple(kw["snr_db_range"])
+    np.random.seed(meta["mix"]["seed"])
+    out = mx.get_dataset(mx.MixedSNRDecoderConfig(**kw))
+    assert [str(a.dtype) for a in out] == meta["mix"]["dtypes"]
+    assert [list(a.shape) for a in out] == meta["mix"]["shapes"]
+    assert np.array_equal(out[0], g["mix_train"]) and np.array_equal(out[1], g["mix_test"])
+    assert np.array_equal(np.argmax(out[2], 1), g["mix_train_labels_idx"])
+    assert np.array_equal(np.argmax(out[3], 1), g["mix_random_labels_idx"])
+    assert np.array_equal(out[4], g["mix_random_set"]) and np.array_equal(out[5], g["mix_class_bits"])
+    # rows past samples_per_snr * n_snr stay zero in every class (samples_per_snr quirk)
+    assert len(mx.get_dataset.last_test_labels) == out[1].shape[0]
+
+
+def test_one_hot(golden):
+    g, _ = golden
+    a = fv.create_one_hot_labels(g["one_hot_in"], 4)
+    assert a.dtype == np.float32 and np.array_equal(a, g["one_hot_out"])
+    h = mx.create_one_hot_labels(g["one_hot_in"], 4)
+    assert h.dtype == np.float16 and np.array_equal(h, g["one_hot_out_mixed"])
+    # reference tests/test_utilities.py:101-143
+    assert np.array_equal(fv.create_one_hot_labels(np.array([0, 1, 2]), 3), np.eye(3))
+    assert fv.create_one_hot_labels(np.array([3]), 5).sum() == 1
+
+
+def test_class_bits(golden):
+    g, _ = golden
+    for b in (3, 7, 8, 10):
+        cb = fv.generate_class_bits(b)
+        assert cb.dtype == np.uint8 and np.array_equal(cb, g[f"class_bits_{b}"])
+    # reference tests/test_utilities.py:72-87, :303-309, :342-348
+    assert fv.generate_class_bits(3).tolist() == [[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1],
+                                                  [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1]]
+    assert fv.generate_class_bits(1).tolist() == [[0], [1]]
+    assert fv.generate_class_bits(15).shape == (32768, 15)
+
+
+# ---------------------------------------------------------------- metrics / utilities
+def test_calculate_error_prints_exactly_like_the_reference(golden):
+    g, meta = golden
+    cfg3 = fv.DecoderConfig(block_length=3, samples_per_class_test=2)
+    text = _stdout(fv.calculate_error, fv.create_one_hot_labels(g["err3_labels_idx"], 8),
+                   g["err3_preds"], fv.generate_class_bits(3), cfg3)
+    assert text == meta["calculate_error_b3_stdout"]
+    cfg5 = fv.DecoderConfig(block_length=5, samples_per_class_test=6)
+    text = _stdout(fv.calculate_error, fv.create_one_hot_labels(g["err5_labels_idx"], 32),
+                   g["err5_preds"], fv.generate_class_bits(5), cfg5)
+    assert text == meta["calculate_error_b5_stdout"]
+
+
+def test_mixed_metrics(golden):
+    g, meta = golden
+    assert mx.calculate_ber(g["err3_preds"], g["err3_labels_idx"], 3) == meta["calculate_ber_b3"]
+    assert mx.calculate_accuracy(g["err3_preds"], g["err3_labels_idx"]) == meta["calculate_accuracy_b3"]
+    assert mx.calculate_ber(g["err5_preds"], g["err5_labels_idx"], 5) == meta["calculate_ber_b5"]
+    assert mx.calculate_accuracy(g["err5_preds"], g["err5_labels_idx"]) == meta["calculate_accuracy_b5"]
+
+
+def test_bit_utilities(golden):
+    _, meta = golden
+    for v, e in meta["binary_to_decimal"]:
+        assert mx.binary_to_decimal(np.array(v)) == e          # LSB-first
+    for d, n, e in meta["extract_bits_single"]:
+        assert mx.extract_bits_single(d, n).tolist() == e
+    for a, b, n, e in meta["hamming"]:
+        assert mx.calculate_hamming_distance_decimal(a, b, n) == e
+    # reference tests/test_utilities.py:193-199, :255-259 (assertions that hold for shipped code)
+    assert mx.extract_bits_single(5, 5).tolist() == [0, 0, 1, 0, 1]
+    assert mx.calculate_hamming_distance_decimal(5, 3, 3) == 2
+
+
+# ---------------------------------------------------------------- model helpers
+def test_initialize_weights_shapes_and_truncation():
+    cfg = fv.DecoderConfig(block_length=8)
+    w, b = fv.initialize_weights(cfg, rng=np.random.RandomState(0))
+    assert [w[k].shape for k in ("h1", "h2", "h3", "out")] == [(16, 128), (128, 64), (64, 32), (32, 256)]
+    assert all(v.dtype == np.float32 for v in w.values())
+    assert all(not v.any() for v in b.values())                       # zero biases
+    for k, fan_in in (("h1", 16), ("h2", 128), ("h3", 64), ("out", 32)):
+        sd = np.sqrt(2.0 / fan_in)
+        assert np.abs(w[k]).max() <= 2 * sd * (1 + 1e-6)              # re-drawn beyond 2 sigma
+        assert 0.7 * sd < w[k].std() < 1.0 * sd
+    Ws, bs = fv.weights_as_lists(w, b)
+    assert [W.shape[0] for W in Ws] == [16, 128, 64, 32] and len(bs) == 4
+    cfg.n_layers = 2
+    assert fv.layer_dims(cfg) == [16, 128, 64, 256]
+
+
+def test_checkpoint_round_trip(tmp_path):
+    cfg = mx.MixedSNRDecoderConfig(block_length=6)
+    w, b = mx.initialize_weights(cfg, rng=np.random.RandomState(1))
+    p = mx.save_model(str(tmp_path / "m" / "mixed_snr_model"), w, b)
+    data = np.load(p)
+    assert sorted(data.files) == sorted(["weights_h1", "weights_h2", "weights_h3", "weights_out",
+                                         "bias_h1", "bias_h2", "bias_h3", "bias_out"])
+    w2, b2 = mx.load_model(str(tmp_path / "m" / "mixed_snr_model"))
+    assert all(np.array_equal(w[k], w2[k]) for k in w) and all(np.array_equal(b[k], b2[k]) for k in b)
+
+
+def test_eval_without_checkpoint_fails_loudly():
+    cfg = mx.MixedSNRDecoderConfig(block_length=6, samples_per_class_test=1)
+    x = np.zeros((4, 12), np.float32)
+    y = mx.create_one_hot_labels(np.zeros(4, int), 64)
+    with pytest.raises(RuntimeError):
+        mx.create_model_graph(cfg, x, y, x, y, train_mode=False, model_load_path=None)
+
+
+def test_decode_path_has_no_cpu_fallback():
+    """Without a HIP device the product path must raise, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    cfg = fv.DecoderConfig(block_length=6)
+    w, b = fv.initialize_weights(cfg, rng=np.random.RandomState(0))
+    with pytest.raises(nnviterbi_amd.NNViterbiError):
+        fv.predict(np.zeros((2, 12), np.float32), w, b)
+    with pytest.raises(nnviterbi_amd.NNViterbiError):
+        fv.multilayer_perceptron(np.zeros((2, 12), np.float32), w, b)
+
+
+def test_trainer_reduces_the_loss_on_cpu():
+    """Section 8f rank 1 (trainer): tiny CPU run, loss goes down, shapes kept."""
+    from nnviterbi_amd.training import train_network
+    cfg = fv.DecoderConfig(block_length=6, samples_per_class_train=8, samples_per_class_test=1,
+                           training_epochs=3, batch_size=64, learning_rate=0.01)
+    np.random.seed(0)
+    tr, trl, _, _, _ = fv.train_test_dataset(cfg)
+    w0, b0 = fv.initialize_weights(cfg, rng=np.random.RandomState(0))
+    text = _stdout(lambda: train_network(cfg, tr, trl, w0, b0))
+    costs = [float(line.split("=")[1]) for line in text.strip().splitlines()]
+    assert len(costs) == 3 and costs[-1] < costs[0]
+    assert text.startswith("Epoch: 0001 | cost = ")

@@ -1,0 +1,137 @@
+"""The oracle against (a) golden vectors produced by the reference itself
+(numpy half: encoders, channel, codebook, metrics) and (b) its own float64
+forward fixtures.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import fnn_oracle as O
+
+
+def test_encoders_match_reference_vectors(golden):
+    g, meta = golden
+    for i in range(meta["n_enc_inputs"]):
+        bits = g[f"enc_in_{i}"]
+        assert np.array_equal(O.encode_57(bits), g[f"enc57_out_{i}"])
+        if len(bits) >= 6:
+            assert np.array_equal(O.encode_133171(bits), g[f"enc133171_out_{i}"])
+
+
+def test_encoder_known_answers_from_survey():
+    # SURVEY.md section 4, captured from the shipped reference code
+    assert O.encode_57([1, 0, 0, 0, 0]).tolist() == [1, 1, 0, 1, 1, 1, 0, 0, 0, 0]
+    assert O.encode_57([1, 1, 0, 1, 0]).tolist() == [1, 0, 1, 0, 1, 0, 0, 0, 0, 1]
+    assert O.encode_133171([1] + [0] * 9).tolist() == \
+        [1, 1, 0, 1, 1, 1, 1, 1, 0, 0, 1, 0, 1, 1, 0, 0, 0, 0, 0, 0]
+    assert O.encode_133171([1, 0, 1, 1, 0, 1, 0, 1, 1, 0]).tolist() == \
+        [1, 1, 0, 1, 0, 0, 0, 1, 1, 0, 0, 1, 0, 1, 1, 0, 0, 0, 0, 1]
+    assert O.encode_133171(np.ones(10, dtype=int)).tolist() == \
+        [1, 1, 1, 0, 0, 1, 1, 0, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1]
+
+
+def test_short_inputs_raise_like_the_reference(golden):
+    _, meta = golden
+    assert meta["short_input_errors"] == {"encode_57": "IndexError", "encode_133171": "IndexError"}
+    with pytest.raises(IndexError):
+        O.encode_57(np.zeros(1, dtype=np.int32))
+    with pytest.raises(IndexError):
+        O.encode_133171(np.zeros(5, dtype=np.int32))
+
+
+def test_codebooks(golden):
+    g, _ = golden
+    for b in (3, 7, 8, 10):
+        cb = O.generate_class_bits(b)
+        assert np.array_equal(cb, g[f"class_bits_{b}"])
+        assert np.array_equal(np.stack([O.encode_57(r) for r in cb]), g[f"codebook57_{b}"])
+        if b >= 6 and b <= 8:
+            assert np.array_equal(np.stack([O.encode_133171(r) for r in cb]),
+                                  g[f"codebook133171_{b}"])
+
+
+def test_sigma_table(golden):
+    _, meta = golden
+    for db, s in meta["sigma_by_snr_db"].items():
+        assert O.sigma_from_snr_db(float(db)) == pytest.approx(s, rel=0, abs=1e-16)
+    assert O.sigma_from_snr_db(2.0) == pytest.approx(0.5616748812614791, abs=1e-15)
+
+
+def test_modulate_awgn(golden):
+    g, meta = golden
+    np.random.seed(7)
+    out = O.modulate_awgn(g["awgn_in"], 0.5616748812614791)
+    assert out.dtype == np.float64 and meta["awgn_out_dtype"] == "float64"
+    assert np.array_equal(out, g["awgn_out_seed7"])
+
+
+def test_error_counters_match_reference_metrics(golden):
+    g, meta = golden
+    c = O.error_counters(g["err3_preds"], g["err3_labels_idx"], 3)
+    assert c.tolist() == [4, 2, 48, 16]                      # "Total Bit Errors: 4/48", FER 0.125
+    assert c[0] / c[2] == pytest.approx(meta["calculate_ber_b3"])
+    assert 1 - c[1] / c[3] == pytest.approx(meta["calculate_accuracy_b3"])
+    c5 = O.error_counters(g["err5_preds"], g["err5_labels_idx"], 5)
+    assert c5[0] / c5[2] == pytest.approx(meta["calculate_ber_b5"])
+    assert 1 - c5[1] / c5[3] == pytest.approx(meta["calculate_accuracy_b5"])
+
+
+def test_class_to_bits_is_msb_first():
+    assert O.class_to_bits(np.array([5]), 5).tolist() == [[0, 0, 1, 0, 1]]
+    assert O.class_to_bits(np.array([1, 64]), 7).tolist() == [[0, 0, 0, 0, 0, 0, 1],
+                                                              [1, 0, 0, 0, 0, 0, 0]]
+
+
+def _case(fg, name, depth):
+    Ws = [fg[f"{name}_W{i}"] for i in range(depth)]
+    bs = [fg[f"{name}_b{i}"] for i in range(depth)]
+    return Ws, bs, fg[f"{name}_x"], fg[f"{name}_labels"]
+
+
+CASES = [("b8_l3", 4, 8), ("b7_l3", 4, 7), ("b10_l2", 3, 10), ("b3_l3", 4, 3)]
+
+
+@pytest.mark.parametrize("name,depth,b", CASES)
+def test_fp64_forward_fixture_is_reproduced(forward_golden, name, depth, b):
+    Ws, bs, x, labels = _case(forward_golden, name, depth)
+    cls, bits, out = O.decode(x, Ws, bs, b, np.float64)
+    assert np.array_equal(cls, forward_golden[f"{name}_cls"])
+    assert np.allclose(out[:16], forward_golden[f"{name}_out_head"], rtol=0, atol=1e-12)
+    assert np.array_equal(O.error_counters(cls, labels, b), forward_golden[f"{name}_counters"])
+    assert np.array_equal(bits, O.class_to_bits(cls, b))
+
+
+@pytest.mark.parametrize("name,depth,b", CASES)
+def test_fp32_oracles_agree_with_fp64_within_tolerance(forward_golden, name, depth, b):
+    """numpy-fp32 and C-fp32 restatements: outputs within 1e-5 of the fp64 twin,
+    class differences only on rows whose fp64 top-2 margin is below 1e-5."""
+    Ws, bs, x, labels = _case(forward_golden, name, depth)
+    ref_cls = forward_golden[f"{name}_cls"]
+    margin = forward_golden[f"{name}_margin"]
+    _, _, o64 = O.decode(x, Ws, bs, b, np.float64)
+    cls32, _, o32 = O.decode(x, Ws, bs, b, np.float32)
+    c = O.decode_c(x, Ws, bs, b, labels=labels, want_act=True)
+    for cls, out in ((cls32, o32), (c["cls"], c["act"])):
+        assert np.abs(out - o64).max() < 1e-5
+        bad = cls != ref_cls
+        assert not bad.any() or margin[bad].max() < 1e-5
+    assert np.array_equal(c["bits"], O.class_to_bits(c["cls"], b))
+    assert np.array_equal(c["counters"], O.error_counters(c["cls"], labels, b))
+
+
+def test_c_oracle_k_order_permutation_only_changes_rounding(forward_golden):
+    Ws, bs, x, labels = _case(forward_golden, "b8_l3", 4)
+    rng = np.random.RandomState(0)
+    korder = [rng.permutation(W.shape[0]).astype(np.int32) for W in Ws]
+    a = O.decode_c(x[:64], Ws, bs, 8, want_act=True)
+    p = O.decode_c(x[:64], Ws, bs, 8, want_act=True, korder=korder)
+    assert np.abs(a["act"] - p["act"]).max() < 5e-6
+    assert not np.array_equal(a["act"], p["act"])      # order does matter in fp32
+
+
+def test_argmax_first_maximum_rule():
+    out = np.array([[0.5, 1.0, 1.0, -1.0], [1.0, 1.0, 1.0, 1.0]])
+    assert O.argmax_first(out).tolist() == [1, 0]
+    # saturated output layer in the C oracle: huge bias -> tanhf == 1.0f for all classes
+    W = [np.zeros((2, 4), np.float32), np.zeros((4, 4), np.float32)]
+    b = [np.zeros(4, np.float32), np.full(4, 30.0, np.float32)]
+    r = O.decode_c(np.ones((3, 2), np.float32), W, b, 2)
+    assert r["cls"].tolist() == [0, 0, 0]
