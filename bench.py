@@ -64,14 +64,14 @@ def cpu_baseline(x_dev, labels_dev, Ws, bs, hip_cls, budget_s=12.0):
     probe = 200_000
     xs = x_dev[:probe].cpu().numpy()
     t0 = time.perf_counter()
-    O.decode_c(xs, Ws, bs, TILE_BITS, want_bits=False)
+    O.decode_c(xs, Ws, bs, TILE_BITS, want_bits=False, n_threads=threads)
     rate = probe / (time.perf_counter() - t0)
     n = int(min(x_dev.shape[0], max(probe, rate * budget_s)))
     n -= n % ROWS_PER_BLOCK
     xs = x_dev[:n].cpu().numpy()
     ls = labels_dev[:n].cpu().numpy()
     t0 = time.perf_counter()
-    ref = O.decode_c(xs, Ws, bs, TILE_BITS, labels=ls, want_bits=False)
+    ref = O.decode_c(xs, Ws, bs, TILE_BITS, labels=ls, want_bits=False, n_threads=threads)
     dt = time.perf_counter() - t0
     hip = hip_cls[:n].cpu().numpy()
     mism = int((hip != ref["cls"]).sum())

@@ -305,7 +305,7 @@ def run_network(config: DecoderConfig, training_set: np.ndarray, training_labels
     labels_idx = np.argmax(test_labels, axis=1).astype(np.int32)
     predictions, counters = predict(test_set, weights, biases, labels=labels_idx,
                                     tile_bits=config.block_length)
-    accuracy = 1.0 - counters[1] / max(int(counters[3]), 1)
+    accuracy = (int(counters[3]) - int(counters[1])) / max(int(counters[3]), 1)
     print(f"Accuracy: {accuracy:.4f}")
     run_network.last_model = (weights, biases)
     return predictions

@@ -252,7 +252,7 @@ def _evaluate(model: ModelGraph, x, one_hot_labels, title: str) -> None:
     preds, counters = _fv.predict(x, model.weights, model.biases, labels=labels_idx,
                                   tile_bits=cfg.block_length)
     model.predictions = preds
-    model.accuracy = 1.0 - int(counters[1]) / max(int(counters[3]), 1)
+    model.accuracy = (int(counters[3]) - int(counters[1])) / max(int(counters[3]), 1)
     model.ber = int(counters[0]) / max(int(counters[2]), 1)
     print(f"{title} Accuracy: {model.accuracy:.4f}")
     print(f"{title} BER: {model.ber:.6f}")

@@ -241,5 +241,22 @@ def decode_c(x, weights, biases, b, labels=None, korder=None, want_act=False,
     return {"cls": cls, "bits": bits, "act": act, "counters": counters}
 
 
-def c_max_threads():
-    return int(load_c().fnn_oracle_max_threads())
+def c_max_threads(cap=16):
+    """Threads for the C oracle: the CPUs this process may use (affinity and
+    cgroup quota), at most ``cap`` (a one-GPU box's CPU share is 16)."""
+    n = int(load_c().fnn_oracle_max_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.999)))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("NNV_CPU_THREADS")
+    if env:
+        return max(1, int(env))
+    return max(1, min(n, cap) if cap else n)

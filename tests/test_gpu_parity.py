@@ -324,7 +324,7 @@ def test_reference_api_predict_and_metrics(cuda_device, golden):
     lines = buf.getvalue().splitlines()
     assert lines[3] == f"Total Bit Errors: {counters[0]}/{counters[2]}"
     assert mx.calculate_ber(preds, labels_idx, 7) == counters[0] / counters[2]
-    assert mx.calculate_accuracy(preds, labels_idx) == 1 - counters[1] / counters[3]
+    assert mx.calculate_accuracy(preds, labels_idx) == (counters[3] - counters[1]) / counters[3]
 
 
 def test_create_model_graph_restore_and_run_graph(cuda_device, tmp_path, golden):
