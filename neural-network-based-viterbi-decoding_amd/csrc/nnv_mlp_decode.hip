@@ -49,17 +49,35 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 
 // acc register r = 4q+e of a 32x32 tile holds neuron 8q + 4*(lane>>5) + e of
 // that M-tile; bias vectors are stored padded to 32 floats per M-tile, so one
-// 16-byte read per q fetches the 4 biases this lane needs.
-template <typename BiasPtr>
-__device__ __forceinline__ void bias_tanh(f32x16 &acc, BiasPtr bias_tile,
-                                          int half) {
+// 16-byte LDS read per q fetches the 4 biases this lane needs.  The bias is the
+// INITIAL VALUE of the accumulator (z = b + sum_k x_k w_k as one fmaf chain):
+// no separate add, no zero-fill moves -- on gfx950 every VALU instruction adds
+// to the kernel time because fp32 MFMAs do not co-execute with VALU work.
+__device__ __forceinline__ f32x16 init_acc(const float *bias_tile, int half) {
+  f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_tile + 8 * q + 4 * half);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[4 * q + e] = tanh_f32(acc[4 * q + e] + bv[e]);
+    for (int e = 0; e < 4; ++e) acc[4 * q + e] = bv[e];
   }
+  return acc;
 }
+
+__device__ __forceinline__ void tanh16(f32x16 &acc) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = tanh_f32(acc[r]);
+}
+
+// fp32 tanh returns exactly +-1.0f beyond |z| ~ 9.011 (1 - tanh z < 2^-25), for
+// libm's tanhf and for tanh_f32 above alike.  The hard decision is therefore
+// taken on the class layer's PRE-activations clamped to +-kTanhSat: tanh is
+// monotone, so argmax_first(clamp(z)) == argmax_first(tanh(z)) including the
+// saturated ties (several classes at exactly 1.0f -> lowest index), and the 256
+// transcendentals per row of the class layer are not spent.  (Two distinct
+// unsaturated z that round to the same fp32 tanh, |dtanh| < 6e-8, are told
+// apart here; that is far inside the 1e-5 near-tie rule of DESIGN.md.)
+constexpr float kTanhSat = 9.011f;
 
 template <int G1>
 __device__ __forceinline__ void load_x(const DecodeParams &p, int64_t tile,
@@ -135,21 +153,22 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     // The packed weights in LDS never change, so LLVM would hoist every
     // fragment read out of this persistent loop (and spill them).  Making the
     // lane offset opaque once per tile keeps the reads next to their MFMAs.
-    int lo = lane * 4;
-    asm volatile("" : "+v"(lo));
+    int lane_opaque = lane;
+    asm volatile("" : "+v"(lane_opaque));
+    const int lo = lane_opaque * 4;  // float offset, provably a multiple of 16 bytes
 
     // ---------------- layer 1: K = n_in (bp steps of 2) -------------------
     f32x16 ha[MTA];
 #pragma unroll
     for (int mt = 0; mt < MTA; ++mt) {
-      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 acc = init_acc(lds + B1OFF + 32 * mt, half);
 #pragma unroll
       for (int g = 0; g < G1; ++g) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(lds + (mt * G1 + g) * kFragGroupFloats + lo);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = mfma32(a[e], xr[4 * g + e], acc);
       }
-      bias_tanh(acc, lds + B1OFF + 32 * mt, half);
+      tanh16(acc);
       ha[mt] = acc;
     }
     if (NHID == 1) {
@@ -162,7 +181,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     if constexpr (NHID >= 2) {
 #pragma unroll
       for (int mt = 0; mt < MTB; ++mt) {
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc = init_acc(lds + B2OFF + 32 * mt, half);
 #pragma unroll
         for (int kt = 0; kt < MTA; ++kt) {
 #pragma unroll
@@ -173,7 +192,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
             for (int e = 0; e < 4; ++e) acc = mfma32(a[e], ha[kt][4 * q + e], acc);
           }
         }
-        bias_tanh(acc, lds + B2OFF + 32 * mt, half);
+        tanh16(acc);
         hb[mt] = acc;
       }
       if (!prefetched) {
@@ -187,7 +206,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     if constexpr (NHID >= 3) {
 #pragma unroll
       for (int mt = 0; mt < MTC; ++mt) {
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc = init_acc(lds + B3OFF + 32 * mt, half);
 #pragma unroll
         for (int kt = 0; kt < MTB; ++kt) {
 #pragma unroll
@@ -198,7 +217,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
             for (int e = 0; e < 4; ++e) acc = mfma32(a[e], hb[kt][4 * q + e], acc);
           }
         }
-        bias_tanh(acc, lds + B3OFF + 32 * mt, half);
+        tanh16(acc);
         hc[mt] = acc;
       }
     }
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     int bidx = 0;
     const int64_t row = tile * kRowsPerTile + j;
     for (int mt = 0; mt < p.mt_out; ++mt) {
-      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
       if (p.out_in_lds) {
         const float *wl = lds + lds_out + mt * KT_OUT * 4 * kFragGroupFloats + lo;
 #pragma unroll
@@ -241,33 +260,34 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
           }
         }
       }
-      bias_tanh(acc, lds + BOOFF + 32 * mt, half);
       const int cbase = 32 * mt + 4 * half;
+      if constexpr (WRITE_ACT) {
+        if (row < p.n_rows) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ci = cbase + 8 * (r >> 2) + (r & 3);
+            if (ci < p.n_classes) p.act[row * p.n_classes + ci] = tanh_f32(acc[r]);
+          }
+        }
+      }
       if (((mt + 1) * 32) <= p.n_classes) {
         // per lane the class index grows with r, and mt grows outside: a
         // strict > keeps the FIRST maximum of this lane's subset
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const bool c = acc[r] > best;
-          best = c ? acc[r] : best;
+          const float zc = __builtin_amdgcn_fmed3f(acc[r], -kTanhSat, kTanhSat);
+          const bool c = zc > best;
+          best = c ? zc : best;
           bidx = c ? cbase + 8 * (r >> 2) + (r & 3) : bidx;
         }
       } else {  // last tile of a class count that is not a multiple of 32
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ci = cbase + 8 * (r >> 2) + (r & 3);
-          const bool c = (ci < p.n_classes) && (acc[r] > best);
-          best = c ? acc[r] : best;
+          const float zc = __builtin_amdgcn_fmed3f(acc[r], -kTanhSat, kTanhSat);
+          const bool c = (ci < p.n_classes) && (zc > best);
+          best = c ? zc : best;
           bidx = c ? ci : bidx;
-        }
-      }
-      if constexpr (WRITE_ACT) {
-        if (row < p.n_rows) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ci = cbase + 8 * (r >> 2) + (r & 3);
-            if (ci < p.n_classes) p.act[row * p.n_classes + ci] = acc[r];
-          }
         }
       }
     }
