@@ -11,7 +11,8 @@ import os
 import subprocess
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_PKG_DIR, "libnnviterbi_hip.so")
+# NNV_LIB: A/B a differently-built library (tuning only); default = the in-tree build
+_LIB_PATH = os.environ.get("NNV_LIB") or os.path.join(_PKG_DIR, "libnnviterbi_hip.so")
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 
 NNV_ABI_VERSION = 1

@@ -43,6 +43,16 @@ __device__ __forceinline__ float tanh_f32(float z) {
   return __builtin_fmaf(-2.0f, r, 1.0f);
 }
 
+__device__ __forceinline__ f32x4 load_a(const float *p) {
+#ifdef NNV_ABLATE_LDSA  // timing experiments only: results are wrong
+  f32x4 v = {1.f, 2.f, 3.f, 4.f};
+  asm volatile("" : "+v"(v) : "v"(p));
+  return v;
+#else
+  return *reinterpret_cast<const f32x4 *>(p);
+#endif
+}
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -64,9 +74,27 @@ __device__ __forceinline__ f32x16 init_acc(const float *bias_tile, int half) {
   return acc;
 }
 
+// 16 tanh in stages of NNV_TANH_ILP independent values, so that one wave's
+// transcendental latencies overlap instead of forming one dependent chain.
+#ifndef NNV_TANH_ILP
+#define NNV_TANH_ILP 8
+#endif
 __device__ __forceinline__ void tanh16(f32x16 &acc) {
+#ifdef NNV_ABLATE_TANH  // timing experiments only: results are wrong
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = tanh_f32(acc[r]);
+  for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(acc[r]));
+  return;
+#endif
+#pragma unroll
+  for (int r0 = 0; r0 < 16; r0 += NNV_TANH_ILP) {
+    float e[NNV_TANH_ILP];
+#pragma unroll
+    for (int i = 0; i < NNV_TANH_ILP; ++i) e[i] = __builtin_amdgcn_exp2f(acc[r0 + i] * 2.8853900817779268f);
+#pragma unroll
+    for (int i = 0; i < NNV_TANH_ILP; ++i) e[i] = __builtin_amdgcn_rcpf(1.0f + e[i]);
+#pragma unroll
+    for (int i = 0; i < NNV_TANH_ILP; ++i) acc[r0 + i] = __builtin_fmaf(-2.0f, e[i], 1.0f);
+  }
 }
 
 // fp32 tanh returns exactly +-1.0f beyond |z| ~ 9.011 (1 - tanh z < 2^-25), for
@@ -102,6 +130,21 @@ __device__ __forceinline__ void load_x(const DecodeParams &p, int64_t tile,
   }
 }
 
+#ifdef NNV_DIAG  // separate diagnostic build only: per-phase s_memtime sums of (block 0, wave 0)
+__device__ unsigned long long g_diag[16];
+#define NNV_STAMP(slot)                                                                  \
+  do {                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    unsigned long long t_;                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    diag_sum[slot] += t_ - diag_last;                                                    \
+    diag_last = t_;                                                                      \
+  } while (0)
+#else
+#define NNV_STAMP(slot) do {} while (0)
+#endif
+
 template <int G1, int NHID, int MTA, int MTB, int MTC, int NT, bool WRITE_ACT>
 __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -119,6 +162,9 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   const int out_floats = p.mt_out * KT_OUT * 4 * kFragGroupFloats;
   const int bias_floats = (BOOFF - HIDF) + 32 * p.mt_out;
   const int lds_out = BOOFF + 32 * p.mt_out;  // output groups (if resident)
+  // one 32-bit work counter behind the packed network (decode_plan reserves it)
+  unsigned *tile_ctr = reinterpret_cast<unsigned *>(lds + lds_out + (p.out_in_lds ? out_floats : 0));
+  if (threadIdx.x == 0) *tile_ctr = 0u;
 
   // ---- stage the packed network into LDS (once per persistent workgroup) --
   {
@@ -139,15 +185,31 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31;
   const int half = lane >> 5;
-  const int64_t tstride = static_cast<int64_t>(gridDim.x) * WAVES;
-  int64_t tile = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
+  // Tiles are dealt to the waves of a workgroup on demand (LDS counter): the
+  // SIMD's issue arbitration favours older waves, so a static tile split ends
+  // with the favoured waves idle while the others still have work.  Workgroup
+  // w owns tiles w, w+G, w+2G, ... so all CUs sweep HBM together.
+  auto grab_tile = [&]() -> int64_t {
+    unsigned k = 0;
+    if (lane == 0) k = atomicAdd(tile_ctr, 1u);
+    k = __builtin_amdgcn_readfirstlane(k);
+    return static_cast<int64_t>(blockIdx.x) + static_cast<int64_t>(k) * gridDim.x;
+  };
+  (void)wave;
+  (void)WAVES;
+  int64_t tile = grab_tile();
 
   unsigned bit_err = 0, frame_err = 0;
   float xr[4 * G1];
   if (tile < p.n_tiles) load_x<G1>(p, tile, j, half, xr);
+#ifdef NNV_DIAG
+  unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long diag_last = __builtin_amdgcn_s_memtime();
+  unsigned long long diag_tiles = 0;
+#endif
 
   while (tile < p.n_tiles) {
-    const int64_t next_tile = tile + tstride;
+    const int64_t next_tile = grab_tile();
     float xn[4 * G1];
     bool prefetched = false;
     // The packed weights in LDS never change, so LLVM would hoist every
@@ -157,6 +219,10 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     asm volatile("" : "+v"(lane_opaque));
     const int lo = lane_opaque * 4;  // float offset, provably a multiple of 16 bytes
 
+    const int64_t row = tile * kRowsPerTile + j;
+    int label = 0;
+    if (p.labels && half == 0 && row < p.n_rows) label = p.labels[row];  // needed only in the epilogue
+    NNV_STAMP(0);  // loop top / x wait
     // ---------------- layer 1: K = n_in (bp steps of 2) -------------------
     f32x16 ha[MTA];
 #pragma unroll
@@ -164,7 +230,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       f32x16 acc = init_acc(lds + B1OFF + 32 * mt, half);
 #pragma unroll
       for (int g = 0; g < G1; ++g) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(lds + (mt * G1 + g) * kFragGroupFloats + lo);
+        const f32x4 a = load_a(lds + (mt * G1 + g) * kFragGroupFloats + lo);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = mfma32(a[e], xr[4 * g + e], acc);
       }
@@ -176,6 +242,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       prefetched = true;
     }
 
+    NNV_STAMP(1);  // layer 1
     // ---------------- layer 2 ---------------------------------------------
     f32x16 hb[NHID >= 2 ? MTB : 1];
     if constexpr (NHID >= 2) {
@@ -186,8 +253,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         for (int kt = 0; kt < MTA; ++kt) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(
-                lds + W1F + ((mt * MTA + kt) * 4 + q) * kFragGroupFloats + lo);
+            const f32x4 a = load_a(lds + W1F + ((mt * MTA + kt) * 4 + q) * kFragGroupFloats + lo);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = mfma32(a[e], ha[kt][4 * q + e], acc);
           }
@@ -201,6 +267,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       }
     }
 
+    NNV_STAMP(2);  // layer 2
     // ---------------- layer 3 ---------------------------------------------
     f32x16 hc[NHID >= 3 ? MTC : 1];
     if constexpr (NHID >= 3) {
@@ -211,8 +278,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         for (int kt = 0; kt < MTB; ++kt) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(
-                lds + W1F + W2F + ((mt * MTB + kt) * 4 + q) * kFragGroupFloats + lo);
+            const f32x4 a = load_a(lds + W1F + W2F + ((mt * MTB + kt) * 4 + q) * kFragGroupFloats + lo);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = mfma32(a[e], hb[kt][4 * q + e], acc);
           }
@@ -222,6 +288,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       }
     }
 
+    NNV_STAMP(3);  // layer 3
     // ---------------- output layer + running first-max argmax -------------
     auto &hlast = [&]() -> auto & {
       if constexpr (NHID == 1) return ha;
@@ -230,7 +297,6 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     }();
     float best = -__builtin_inff();
     int bidx = 0;
-    const int64_t row = tile * kRowsPerTile + j;
     for (int mt = 0; mt < p.mt_out; ++mt) {
       f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
       if (p.out_in_lds) {
@@ -239,7 +305,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         for (int kt = 0; kt < KT_OUT; ++kt) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(wl + (kt * 4 + q) * kFragGroupFloats);
+            const f32x4 a = load_a(wl + (kt * 4 + q) * kFragGroupFloats);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               acc = mfma32(a[e], hlast[kt][4 * q + e], acc);
@@ -270,7 +336,15 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
           }
         }
       }
-      if (((mt + 1) * 32) <= p.n_classes) {
+#ifdef NNV_ABLATE_ARGMAX  // timing experiments only: results are wrong
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(acc[r]));
+      best = acc[0];
+      if (false)
+#else
+      if (((mt + 1) * 32) <= p.n_classes)
+#endif
+      {
         // per lane the class index grows with r, and mt grows outside: a
         // strict > keeps the FIRST maximum of this lane's subset
 #pragma unroll
@@ -292,6 +366,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       }
     }
 
+    NNV_STAMP(4);  // class layer
     // ---------------- merge the two lane halves, emit ----------------------
     {
       const float ov = __shfl_xor(best, 32);
@@ -308,7 +383,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
           pb[t] = static_cast<uint8_t>((bidx >> (p.tile_bits - 1 - t)) & 1);
       }
       if (p.labels) {
-        const unsigned diff = static_cast<unsigned>(bidx) ^ static_cast<unsigned>(p.labels[row]);
+        const unsigned diff = static_cast<unsigned>(bidx) ^ static_cast<unsigned>(label);
         bit_err += __builtin_popcount(diff);
         frame_err += diff != 0u;
       }
@@ -319,7 +394,17 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       for (int s = 0; s < 4 * G1; ++s) xr[s] = xn[s];
     }
     tile = next_tile;
+    NNV_STAMP(5);  // epilogue
+#ifdef NNV_DIAG
+    ++diag_tiles;
+#endif
   }
+#ifdef NNV_DIAG
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int i = 0; i < 8; ++i) g_diag[i] = diag_sum[i];
+    g_diag[8] = diag_tiles;
+  }
+#endif
 
   // ---------------- error counters: one atomic pair per wave --------------
   if (p.counters) {
@@ -364,7 +449,11 @@ struct KernelEntry {
   NNV_K(G1, 1, 4, 1, 1, 512, true), NNV_K(G1, 2, 4, 2, 1, 512, true),        \
   NNV_K(G1, 3, 4, 2, 1, 512, true)
 
+#ifdef NNV_DIAG
+const KernelEntry kKernels[] = {NNV_FAMILY(1), NNV_FAMILY(2), NNV_FAMILY(3), NNV_K(2, 3, 4, 2, 1, 256, false)};
+#else
 const KernelEntry kKernels[] = {NNV_FAMILY(1), NNV_FAMILY(2), NNV_FAMILY(3)};
+#endif
 
 const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act) {
   const int mta = s.mt[0];
@@ -384,7 +473,7 @@ int pick_threads(const PackedShape &s) {
   static const int forced = [] {
     const char *e = getenv("NNV_THREADS");
     const int v = e ? atoi(e) : 0;
-    return (v == 512 || v == 1024) ? v : 0;
+    return (v == 256 || v == 512 || v == 1024) ? v : 0;
   }();
   if (forced) return forced;
   const KernelEntry *k = find_kernel(s, 1024, false);
@@ -412,9 +501,9 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
                        int lds_limit, LaunchPlan *plan) {
   if (!find_kernel(s, 512, false)) return NNV_ERR_UNSUPPORTED_SHAPE;
   const int64_t base_floats = s.hid_floats + s.bias_floats;
-  if (base_floats * 4 > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
-  plan->out_in_lds = ((base_floats + s.out_floats) * 4 <= lds_limit) ? 1 : 0;
-  plan->lds_bytes = static_cast<int32_t>((base_floats + (plan->out_in_lds ? s.out_floats : 0)) * 4);
+  if (base_floats * 4 + 16 > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
+  plan->out_in_lds = ((base_floats + s.out_floats) * 4 + 16 <= lds_limit) ? 1 : 0;
+  plan->lds_bytes = static_cast<int32_t>((base_floats + (plan->out_in_lds ? s.out_floats : 0)) * 4) + 16;  // + work counter
   plan->threads = pick_threads(s);
   const int64_t n_tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int waves = plan->threads / 64;
@@ -451,3 +540,9 @@ nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
 }
 
 }  // namespace nnv
+
+#ifdef NNV_DIAG
+extern "C" int nnv_debug_read_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(nnv::g_diag), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
