@@ -112,6 +112,22 @@ int32_t nnv_mlp_decode_f32(const nnv_mlp_handle *h, const float *x_dev,
                            uint64_t *counters_dev, void *stream);
 
 /*
+ * The same launch with error counters kept PER SNR BIN, for mixed-SNR sweeps
+ * (BASELINE config 4; the reference evaluates one SNR per run,
+ * src/fnn_viterbi_mixed_snr.py:452-460,813-845): row r of this call belongs to
+ * block (first_row + r) / rows_per_block and to bin block % n_bins, the rule
+ * nnv_awgn_generate_f32 uses to pick sigma.  counters_dev is uint64[n_bins][4],
+ * each row laid out like nnv_mlp_decode_f32's counters, accumulated.
+ * 1 <= n_bins <= 16.  labels_dev and counters_dev are required.
+ */
+int32_t nnv_mlp_decode_binned_f32(const nnv_mlp_handle *h, const float *x_dev,
+                                  int64_t n_rows, int32_t tile_bits,
+                                  const int32_t *labels_dev, int32_t *cls32_dev,
+                                  uint64_t *counters_dev, int64_t first_row,
+                                  int64_t rows_per_block, int32_t n_bins,
+                                  void *stream);
+
+/*
  * Debug / parity entry: the tanh'd output layer itself,
  * multilayer_perceptron(x, W, b) (src/fnn_viterbi.py:471-510).
  *  out_dev  [n_rows][dims[depth]] fp32.  Slow (strided stores).

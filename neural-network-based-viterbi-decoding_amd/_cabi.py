@@ -23,7 +23,7 @@ NNV_CODE_133171 = 1
 
 EXPORTED_SYMBOLS = (
     "nnv_abi_version", "nnv_status_string", "nnv_device_count",
-    "nnv_mlp_prepack", "nnv_mlp_free", "nnv_mlp_decode_f32",
+    "nnv_mlp_prepack", "nnv_mlp_free", "nnv_mlp_decode_f32", "nnv_mlp_decode_binned_f32",
     "nnv_mlp_forward_f32", "nnv_awgn_generate_f32",
     "nnv_mlp_decode_f32_timed", "nnv_mlp_launch_info",
 )
@@ -83,6 +83,10 @@ def load_library() -> ctypes.CDLL:
     lib.nnv_mlp_decode_f32.argtypes = [
         c.c_void_p, c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_void_p,
         c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.nnv_mlp_decode_binned_f32.restype = c.c_int32
+    lib.nnv_mlp_decode_binned_f32.argtypes = [
+        c.c_void_p, c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_void_p,
+        c.c_void_p, c.c_int64, c.c_int64, c.c_int32, c.c_void_p]
     lib.nnv_mlp_forward_f32.restype = c.c_int32
     lib.nnv_mlp_forward_f32.argtypes = [
         c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]

@@ -107,6 +107,9 @@ nnv_status make_params(const nnv_mlp_handle *h, const float *x_dev, int64_t n_ro
   p->mt_out = s.mt_out;
   p->n_classes = s.n_classes;
   p->out_in_lds = plan->out_in_lds;
+  p->n_bins = 1;
+  p->rows_per_block = 1;
+  p->first_row = 0;
   return NNV_OK;
 }
 
@@ -205,6 +208,30 @@ int32_t nnv_mlp_decode_f32(const nnv_mlp_handle *h, const float *x_dev, int64_t 
   p.cls64 = cls64_dev;
   p.bits = bits_dev;
   p.counters = reinterpret_cast<unsigned long long *>(counters_dev);
+  return nnv::decode_launch(h->shape, p, plan, false, static_cast<hipStream_t>(stream));
+}
+
+int32_t nnv_mlp_decode_binned_f32(const nnv_mlp_handle *h, const float *x_dev, int64_t n_rows,
+                                  int32_t tile_bits, const int32_t *labels_dev, int32_t *cls32_dev,
+                                  uint64_t *counters_dev, int64_t first_row, int64_t rows_per_block,
+                                  int32_t n_bins, void *stream) {
+  if (!h || n_rows < 0 || first_row < 0 || rows_per_block < 1) return NNV_ERR_INVALID_ARGUMENT;
+  if (n_bins < 1 || n_bins > nnv::kMaxBins) return NNV_ERR_INVALID_ARGUMENT;
+  if (n_rows == 0) return NNV_OK;
+  if (!x_dev || !labels_dev || !counters_dev) return NNV_ERR_INVALID_ARGUMENT;
+  if (tile_bits < 1 || tile_bits > 30 || (1LL << tile_bits) < h->shape.n_classes)
+    return NNV_ERR_INVALID_ARGUMENT;
+  DecodeParams p;
+  LaunchPlan plan;
+  const nnv_status st = make_params(h, x_dev, n_rows, &p, &plan);
+  if (st != NNV_OK) return st;
+  p.tile_bits = tile_bits;
+  p.labels = labels_dev;
+  p.cls32 = cls32_dev;
+  p.counters = reinterpret_cast<unsigned long long *>(counters_dev);
+  p.n_bins = n_bins;
+  p.rows_per_block = rows_per_block;
+  p.first_row = first_row;
   return nnv::decode_launch(h->shape, p, plan, false, static_cast<hipStream_t>(stream));
 }
 

@@ -68,8 +68,16 @@ struct DecodeParams {
   int64_t *cls64;
   uint8_t *bits;
   float *act;
-  unsigned long long *counters;
+  unsigned long long *counters;  // [4] or, with n_bins > 1, [n_bins][4]
+  // mixed-SNR sweeps (BASELINE config 4): counters are kept per SNR bin,
+  // bin = ((first_row + row) / rows_per_block) % n_bins
+  int32_t n_bins;
+  int64_t rows_per_block;
+  int64_t first_row;
 };
+
+constexpr int kMaxBins = 16;
+constexpr int kLdsTailBytes = 16 + kMaxBins * 16;  // work counter + per-bin {bit, frame, rows, pad}
 
 struct LaunchPlan {
   int32_t threads;

@@ -164,7 +164,9 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   const int lds_out = BOOFF + 32 * p.mt_out;  // output groups (if resident)
   // one 32-bit work counter behind the packed network (decode_plan reserves it)
   unsigned *tile_ctr = reinterpret_cast<unsigned *>(lds + lds_out + (p.out_in_lds ? out_floats : 0));
+  unsigned *bin_ctr = tile_ctr + 4;  // [kMaxBins][4] u32, used only when n_bins > 1
   if (threadIdx.x == 0) *tile_ctr = 0u;
+  if (threadIdx.x < kMaxBins * 4) bin_ctr[threadIdx.x] = 0u;
 
   // ---- stage the packed network into LDS (once per persistent workgroup) --
   {
@@ -384,8 +386,15 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       }
       if (p.labels) {
         const unsigned diff = static_cast<unsigned>(bidx) ^ static_cast<unsigned>(label);
-        bit_err += __builtin_popcount(diff);
-        frame_err += diff != 0u;
+        if (p.n_bins > 1) {  // per-SNR-bin counters (mixed-SNR sweep): LDS atomics
+          const int bin = static_cast<int>(((p.first_row + row) / p.rows_per_block) % p.n_bins);
+          atomicAdd(bin_ctr + 4 * bin + 0, static_cast<unsigned>(__builtin_popcount(diff)));
+          atomicAdd(bin_ctr + 4 * bin + 1, diff != 0u ? 1u : 0u);
+          atomicAdd(bin_ctr + 4 * bin + 2, 1u);
+        } else {
+          bit_err += __builtin_popcount(diff);
+          frame_err += diff != 0u;
+        }
       }
     }
 
@@ -407,7 +416,19 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #endif
 
   // ---------------- error counters: one atomic pair per wave --------------
-  if (p.counters) {
+  if (p.counters && p.n_bins > 1) {
+    __syncthreads();
+    if (threadIdx.x < p.n_bins) {
+      const unsigned *c = bin_ctr + 4 * threadIdx.x;
+      unsigned long long *g = p.counters + 4 * threadIdx.x;
+      if (c[2]) {
+        atomicAdd(g + 0, static_cast<unsigned long long>(c[0]));
+        atomicAdd(g + 1, static_cast<unsigned long long>(c[1]));
+        atomicAdd(g + 2, static_cast<unsigned long long>(c[2]) * p.tile_bits);
+        atomicAdd(g + 3, static_cast<unsigned long long>(c[2]));
+      }
+    }
+  } else if (p.counters) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       bit_err += __shfl_xor(bit_err, off);
@@ -501,9 +522,9 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
                        int lds_limit, LaunchPlan *plan) {
   if (!find_kernel(s, 512, false)) return NNV_ERR_UNSUPPORTED_SHAPE;
   const int64_t base_floats = s.hid_floats + s.bias_floats;
-  if (base_floats * 4 + 16 > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
-  plan->out_in_lds = ((base_floats + s.out_floats) * 4 + 16 <= lds_limit) ? 1 : 0;
-  plan->lds_bytes = static_cast<int32_t>((base_floats + (plan->out_in_lds ? s.out_floats : 0)) * 4) + 16;  // + work counter
+  if (base_floats * 4 + kLdsTailBytes > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
+  plan->out_in_lds = ((base_floats + s.out_floats) * 4 + kLdsTailBytes <= lds_limit) ? 1 : 0;
+  plan->lds_bytes = static_cast<int32_t>((base_floats + (plan->out_in_lds ? s.out_floats : 0)) * 4) + kLdsTailBytes;  // + work counter, bin counters
   plan->threads = pick_threads(s);
   const int64_t n_tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int waves = plan->threads / 64;

@@ -136,6 +136,30 @@ class PackedMLP:
         _cabi.check(st, "nnv_mlp_decode_f32")
         return {"cls32": cls32, "cls64": cls64, "bits": bits, "counters": counters}
 
+    def decode_binned(self, x: torch.Tensor, labels: torch.Tensor, n_bins: int,
+                      rows_per_block: int, first_row: int = 0,
+                      counters: Optional[torch.Tensor] = None, tile_bits: Optional[int] = None,
+                      want_cls32: bool = False) -> Dict[str, Optional[torch.Tensor]]:
+        """Decode with error counters per SNR bin (mixed-SNR sweep, BASELINE config 4):
+        row r -> block (first_row + r) // rows_per_block -> bin block % n_bins.
+        ``counters`` int64 [n_bins, 4] is ADDED to (created zeroed if None)."""
+        self._check_x(x)
+        n = x.shape[0]
+        b = self.tile_bits() if tile_bits is None else int(tile_bits)
+        if labels.dtype != torch.int32 or labels.shape != (n,) or labels.device != x.device:
+            raise ValueError("labels must be int32 [N] on x's device")
+        if counters is None:
+            counters = torch.zeros((n_bins, 4), dtype=torch.int64, device=x.device)
+        if counters.dtype != torch.int64 or tuple(counters.shape) != (n_bins, 4):
+            raise ValueError("counters must be int64 [n_bins, 4]")
+        cls32 = torch.empty(n, dtype=torch.int32, device=x.device) if want_cls32 else None
+        with torch.cuda.device(self.device):
+            st = self._lib.nnv_mlp_decode_binned_f32(
+                self._handle, _ptr(x), n, b, _ptr(labels.contiguous()), _ptr(cls32), _ptr(counters),
+                int(first_row), int(rows_per_block), int(n_bins), _stream_ptr(self.device))
+        _cabi.check(st, "nnv_mlp_decode_binned_f32")
+        return {"cls32": cls32, "counters": counters}
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """The tanh'd output layer [N, n_classes] (debug / parity; slow)."""
         self._check_x(x)

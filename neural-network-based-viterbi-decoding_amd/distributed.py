@@ -86,3 +86,31 @@ def rates(counters) -> Tuple[float, float]:
     ber = c[0] / c[2] if c[2] else float("nan")
     fer = c[1] / c[3] if c[3] else float("nan")
     return ber, fer
+
+
+def decode_blocks_sharded(net, code: str, tile_bits: int, n_blocks_total: int, rows_per_block: int,
+                          sigmas, seed: int, rank: int = 0, world_size: int = 1,
+                          chunk_rows: int = 1 << 26, device=None) -> torch.Tensor:
+    """BASELINE config 4 driver: this rank's contiguous share of ``n_blocks_total`` synthetic
+    blocks (block i at SNR bin i % len(sigmas)) is generated on the device and decoded chunk by
+    chunk (at most ``chunk_rows`` rows resident at a time: 102 GB of input per GPU at full size
+    would fit, but need not be resident).  Returns this rank's counters int64 [n_bins, 4];
+    combine ranks with :func:`all_reduce_counters`."""
+    from .decoder import generate_awgn_blocks
+    import numpy as np
+    sig = np.atleast_1d(np.asarray(sigmas, dtype=np.float32))
+    n_bins = int(sig.size)
+    first_block, n_blocks = block_shard(n_blocks_total, rank, world_size)
+    first_row = first_block * rows_per_block
+    n_rows = n_blocks * rows_per_block
+    dev = net.device if device is None else torch.device(device)
+    counters = torch.zeros((n_bins, 4), dtype=torch.int64, device=dev)
+    done = 0
+    while done < n_rows:
+        m = min(int(chunk_rows), n_rows - done)
+        x, labels = generate_awgn_blocks(code, tile_bits, m, sig, seed, first_row=first_row + done,
+                                         rows_per_block=rows_per_block, device=dev)
+        net.decode_binned(x, labels, n_bins, rows_per_block, first_row=first_row + done,
+                          counters=counters, tile_bits=tile_bits)
+        done += m
+    return counters

@@ -306,6 +306,38 @@ def test_full_size_round_trip_and_counter_identities(cuda_device):
     net.close()
 
 
+# ------------------------------------------------------------------ BASELINE configs[3]: mixed-SNR sweep, reduced size
+def test_mixed_snr_sweep_per_bin_counters(cuda_device):
+    """(133,171) block_len=1024 = 128 tiles of b=8 per block, block i at SNR (i mod 7) dB.
+    Full size is 100 M blocks over 8 GPUs; here 210 blocks, single call vs chunked/sharded."""
+    from nnviterbi_amd import distributed as nd
+    b, rpb, n_blocks, seed = 8, 128, 210, 77
+    sig = np.array([O.sigma_from_snr_db(d) for d in range(7)], dtype=np.float32)
+    Ws, bs = matched_filter_network(b, "133171")
+    net = PackedMLP(Ws, bs)
+    n = n_blocks * rpb
+    x, lab = generate_awgn_blocks("133171", b, n, sig, seed, rows_per_block=rpb)
+    r = net.decode_binned(x, lab, 7, rpb, want_cls32=True)
+    cls, labels = r["cls32"].cpu().numpy(), lab.cpu().numpy()
+    bins = (np.arange(n) // rpb) % 7
+    want = np.stack([O.error_counters(cls[bins == k], labels[bins == k], b) for k in range(7)])
+    got = r["counters"].cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.array_equal(got.sum(0), net.decode(x, labels=lab, tile_bits=b)["counters"].cpu().numpy())
+    ber = got[:, 0] / got[:, 2]
+    assert np.all(np.diff(ber) < 0)                  # BER falls monotonically from 0 dB to 6 dB
+    # oracle on the same rows (bounded sample: first 3 blocks of every bin)
+    ref = O.decode_c(x.cpu().numpy()[: 21 * rpb], Ws, bs, b, labels=labels[: 21 * rpb], want_bits=False)
+    assert (ref["cls"] != cls[: 21 * rpb]).sum() <= 1
+    # chunked + sharded driver: chunk sizes that do not divide a block, two "ranks"
+    parts = [nd.decode_blocks_sharded(net, "133171", b, n_blocks, rpb, sig, seed, rank=k, world_size=2,
+                                      chunk_rows=1000) for k in range(2)]
+    assert np.array_equal((parts[0] + parts[1]).cpu().numpy(), want)
+    with pytest.raises(nnviterbi_amd.NNViterbiError):
+        net.decode_binned(x, lab, 17, rpb)           # more than 16 bins
+    net.close()
+
+
 # ------------------------------------------------------------------ reference-shaped API on the GPU
 def test_reference_api_predict_and_metrics(cuda_device, golden):
     g, _ = golden
