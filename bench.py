@@ -43,7 +43,8 @@ BLOCK_LEN = 64
 TILE_BITS = 8                      # b: largest divisor of 64 that is <= 10
 ROWS_PER_BLOCK = BLOCK_LEN // TILE_BITS
 SNR_DB = 2.0
-F32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md:42
+# /opt/skills/guides/MI355X_MICROARCH.md:42-43: dense MFMA peaks per operand dtype
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}
 SEED = 20240607
 
 
@@ -94,6 +95,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks-per-gpu", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=("f32", "f16x3"), default="f32",
+                    help="f32: exact fp32 MFMA chain (headline, parity reference); "
+                         "f16x3: hi/lo f16 split operands, fp32 accumulate")
     args = ap.parse_args()
 
     rank, local_rank, world = nd.init_from_env()
@@ -113,7 +117,7 @@ def main():
     weights, biases = fv.initialize_weights(cfg, rng=np.random.RandomState(SEED))
     Ws, bs = fv.weights_as_lists(weights, biases)
     dims = fv.layer_dims(cfg)
-    net = PackedMLP(Ws, bs, device=dev)
+    net = PackedMLP(Ws, bs, device=dev, precision=args.precision)
 
     # ---- this rank's blocks (weak scaling: fixed blocks per GPU) ----------
     n_blocks = args.blocks_per_gpu
@@ -163,7 +167,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[2]: (133,171) K=7, block_len=64 as 8 tiles of b=8, "
                             "10M blocks/GPU @ SNR 2 dB, 3-layer FNN 16-128-64-32-256",
@@ -173,8 +177,8 @@ def main():
             },
             "ber": ber, "fer": fer,
             "roofline": {
-                "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision],
+                "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS[args.precision], "traffic": traffic,
                 "kernel_ms_per_launch": launch_s * 1e3,
                 "algorithmic_flop_per_launch": flop_row * n_rows,
                 "algorithmic_bytes_per_launch": bytes_row * n_rows,

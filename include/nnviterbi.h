@@ -42,6 +42,14 @@ typedef enum nnv_status {
   NNV_ERR_OUT_OF_MEMORY = 5
 } nnv_status;
 
+/* Arithmetic of the dense layers (nnv_mlp_prepack_ex). */
+typedef enum nnv_precision {
+  NNV_PRECISION_F32 = 0,   /* fp32 operands, fp32 MFMA: an exact fp32 fmaf chain  */
+  NNV_PRECISION_F16X3 = 1  /* operands split hi+lo into two f16 (22 bits), three
+                              f16 MFMAs per product block, fp32 accumulate:
+                              ~2^-21 relative error per product, ~3x faster    */
+} nnv_precision;
+
 /* Convolutional codes of the reference's generators. */
 typedef enum nnv_code {
   NNV_CODE_57 = 0,     /* encode_57,     src/fnn_viterbi.py:122-154 (quirks kept) */
@@ -82,6 +90,11 @@ int32_t nnv_device_count(void);
  * nnv_mlp_free.
  */
 int32_t nnv_mlp_prepack(const nnv_mlp_desc *net, nnv_mlp_handle **out);
+
+/* Same, choosing the arithmetic (nnv_precision).  nnv_mlp_prepack == F32.
+ * F16X3 needs every |weight| < 65504 (f16 range) and inputs within it. */
+int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision,
+                           nnv_mlp_handle **out);
 
 int32_t nnv_mlp_free(nnv_mlp_handle *h);
 
@@ -174,7 +187,7 @@ int32_t nnv_mlp_decode_f32_timed(const nnv_mlp_handle *h, const float *x_dev,
 /* Introspection: fills info_host[0..7] = {threads per workgroup, workgroups
  * launched for n_rows, dynamic LDS bytes, VGPRs (0 if unknown), weights
  * resident in LDS (1/0 for the output layer), rows per wave tile, depth,
- * n_classes}. */
+ * n_classes}; info_host[8] = precision (info_host must hold 9 ints). */
 int32_t nnv_mlp_launch_info(const nnv_mlp_handle *h, int64_t n_rows,
                             int32_t *info_host);
 

@@ -20,10 +20,11 @@ NNV_MAX_LAYERS = 4
 NNV_OK = 0
 NNV_CODE_57 = 0
 NNV_CODE_133171 = 1
+NNV_PRECISION = {"f32": 0, "f16x3": 1}
 
 EXPORTED_SYMBOLS = (
     "nnv_abi_version", "nnv_status_string", "nnv_device_count",
-    "nnv_mlp_prepack", "nnv_mlp_free", "nnv_mlp_decode_f32", "nnv_mlp_decode_binned_f32",
+    "nnv_mlp_prepack", "nnv_mlp_prepack_ex", "nnv_mlp_free", "nnv_mlp_decode_f32", "nnv_mlp_decode_binned_f32",
     "nnv_mlp_forward_f32", "nnv_awgn_generate_f32",
     "nnv_mlp_decode_f32_timed", "nnv_mlp_launch_info",
 )
@@ -77,6 +78,8 @@ def load_library() -> ctypes.CDLL:
     lib.nnv_device_count.argtypes = []
     lib.nnv_mlp_prepack.restype = c.c_int32
     lib.nnv_mlp_prepack.argtypes = [c.POINTER(MlpDesc), c.POINTER(c.c_void_p)]
+    lib.nnv_mlp_prepack_ex.restype = c.c_int32
+    lib.nnv_mlp_prepack_ex.argtypes = [c.POINTER(MlpDesc), c.c_int32, c.POINTER(c.c_void_p)]
     lib.nnv_mlp_free.restype = c.c_int32
     lib.nnv_mlp_free.argtypes = [c.c_void_p]
     lib.nnv_mlp_decode_f32.restype = c.c_int32

@@ -20,22 +20,65 @@ bool is_gfx950(const hipDeviceProp_t &prop) { return strstr(prop.gcnArchName, "g
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-nnv_status shape_from_desc(const nnv_mlp_desc *net, PackedShape *s) {
+// IEEE binary16 round-to-nearest-even of a float (host side of the hi/lo split).
+uint16_t f32_to_f16(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return static_cast<uint16_t>(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+  if (x >= 0x477ff000u) return static_cast<uint16_t>(sign | 0x7c00u);  // rounds to inf
+  if (x < 0x33000001u) return static_cast<uint16_t>(sign);              // rounds to 0
+  if (x < 0x38800000u) {                                                // subnormal half
+    const int shift = 126 - static_cast<int>(x >> 23);                  // 14..24
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    m >>= shift;
+    if (rem > halfway || (rem == halfway && (m & 1u))) ++m;
+    return static_cast<uint16_t>(sign | m);
+  }
+  uint32_t h = ((x >> 23) - 112u) << 10 | ((x >> 13) & 0x3ffu);
+  const uint32_t rem = x & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+  return static_cast<uint16_t>(sign | h);
+}
+
+float f16_to_f32(uint16_t h) {
+  const uint32_t sign = (h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+  if (e == 0) {
+    if (m == 0) x = sign;
+    else {
+      e = 113;
+      while (!(m & 0x400u)) { m <<= 1; --e; }
+      x = sign | (e << 23) | ((m & 0x3ffu) << 13);
+    }
+  } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+  else x = sign | ((e + 112u) << 23) | (m << 13);
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
+
+nnv_status shape_from_desc(const nnv_mlp_desc *net, int32_t precision, PackedShape *s) {
   if (net->depth < 2 || net->depth > NNV_MAX_LAYERS) return NNV_ERR_UNSUPPORTED_SHAPE;
   for (int l = 0; l <= net->depth; ++l)
     if (net->dims[l] < 1) return NNV_ERR_INVALID_ARGUMENT;
   for (int l = 0; l < net->depth; ++l)
     if (!net->W_host[l] || !net->b_host[l]) return NNV_ERR_INVALID_ARGUMENT;
+  if (precision != nnv::kPrecF32 && precision != nnv::kPrecF16x3) return NNV_ERR_INVALID_ARGUMENT;
   memset(s, 0, sizeof(*s));
+  s->precision = precision;
   s->depth = net->depth;
   s->nhid = net->depth - 1;
   s->n_in = net->dims[0];
   s->bp = ceil_div(s->n_in, 2);
-  s->g1 = ceil_div(s->bp, 4);
+  s->g1 = precision == nnv::kPrecF32 ? ceil_div(s->bp, 4) : 2 * ceil_div(s->bp, 8);
   for (int i = 0; i < s->nhid; ++i) s->mt[i] = ceil_div(net->dims[i + 1], 32);
   s->n_classes = net->dims[net->depth];
   s->mt_out = ceil_div(s->n_classes, 32);
   s->kt_out = s->mt[s->nhid - 1];
+  // fp32: g1 groups per M-tile; f16x3: (g1/2) k-steps x {hi, lo} = g1 groups as well
   s->hid_floats = static_cast<int64_t>(s->mt[0]) * s->g1 * nnv::kFragGroupFloats;
   for (int i = 1; i < s->nhid; ++i)
     s->hid_floats += static_cast<int64_t>(s->mt[i]) * s->mt[i - 1] * 4 * nnv::kFragGroupFloats;
@@ -44,6 +87,63 @@ nnv_status shape_from_desc(const nnv_mlp_desc *net, PackedShape *s) {
   for (int i = 0; i < s->nhid; ++i) mts += s->mt[i];
   s->bias_floats = 32LL * mts;
   return nnv::decode_supported(*s);
+}
+
+// f16x3 fragment order (nnv_internal.h).  Returns false if a weight is outside the f16 range.
+bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vector<float> *out) {
+  out->assign(static_cast<size_t>(s.hid_floats + s.out_floats + s.bias_floats), 0.f);
+  uint16_t *w = reinterpret_cast<uint16_t *>(out->data());
+  bool in_range = true;
+  auto emit = [&](float v, uint16_t *hi, uint16_t *lo) {
+    if (!(v > -65504.f && v < 65504.f)) in_range = false;
+    const uint16_t h = f32_to_f16(v);
+    *hi = h;
+    *lo = f32_to_f16(v - f16_to_f32(h));
+  };
+  // a group = 64 lanes x 8 halves = 512 uint16; hi group then lo group per k-step
+  {
+    const int M = net->dims[1];
+    const float *W = net->W_host[0];
+    const int ks1 = s.g1 / 2;
+    for (int mt = 0; mt < s.mt[0]; ++mt)
+      for (int ks = 0; ks < ks1; ++ks) {
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int t = 8 * ks + e;
+            const int k = (lane >> 5) * s.bp + t;
+            const int i = 32 * mt + (lane & 31);
+            const float v = (t < s.bp && k < s.n_in && i < M) ? W[static_cast<size_t>(k) * M + i] : 0.f;
+            emit(v, w + lane * 8 + e, w + 512 + lane * 8 + e);
+          }
+        w += 1024;
+      }
+  }
+  for (int l = 1; l < net->depth; ++l) {
+    const int K = net->dims[l], M = net->dims[l + 1];
+    const int KT = s.mt[l - 1];
+    const int MT = (l == net->depth - 1) ? s.mt_out : s.mt[l];
+    const float *W = net->W_host[l];
+    for (int mt = 0; mt < MT; ++mt)
+      for (int kt = 0; kt < KT; ++kt)
+        for (int st = 0; st < 2; ++st) {
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+              const int r = 8 * st + e;
+              const int k = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              const int i = 32 * mt + (lane & 31);
+              const float v = (k < K && i < M) ? W[static_cast<size_t>(k) * M + i] : 0.f;
+              emit(v, w + lane * 8 + e, w + 512 + lane * 8 + e);
+            }
+          w += 1024;
+        }
+  }
+  float *bf = reinterpret_cast<float *>(w);
+  for (int l = 0; l < net->depth; ++l) {
+    const int M = net->dims[l + 1];
+    const int MT = (l == net->depth - 1) ? s.mt_out : s.mt[l];
+    for (int i = 0; i < 32 * MT; ++i) *bf++ = i < M ? net->b_host[l][i] : 0.f;
+  }
+  return in_range;
 }
 
 // Fragment order: see nnv_internal.h.
@@ -143,10 +243,14 @@ int32_t nnv_device_count(void) {
 }
 
 int32_t nnv_mlp_prepack(const nnv_mlp_desc *net, nnv_mlp_handle **out) {
+  return nnv_mlp_prepack_ex(net, NNV_PRECISION_F32, out);
+}
+
+int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision, nnv_mlp_handle **out) {
   if (!net || !out) return NNV_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   PackedShape s;
-  const nnv_status st = shape_from_desc(net, &s);
+  const nnv_status st = shape_from_desc(net, precision, &s);
   if (st != NNV_OK) return st;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return NNV_ERR_NO_DEVICE;
@@ -156,7 +260,11 @@ int32_t nnv_mlp_prepack(const nnv_mlp_desc *net, nnv_mlp_handle **out) {
   if ((s.hid_floats + s.bias_floats) * 4 > kLdsLimitBytes) return NNV_ERR_UNSUPPORTED_SHAPE;
 
   std::vector<float> packed;
-  pack_network(net, s, &packed);
+  if (s.precision == nnv::kPrecF16x3) {
+    if (!pack_network_f16x3(net, s, &packed)) return NNV_ERR_UNSUPPORTED_SHAPE;  // weight outside f16 range
+  } else {
+    pack_network(net, s, &packed);
+  }
   nnv_mlp_handle *h = new (std::nothrow) nnv_mlp_handle;
   if (!h) return NNV_ERR_OUT_OF_MEMORY;
   h->shape = s;
@@ -304,6 +412,7 @@ int32_t nnv_mlp_launch_info(const nnv_mlp_handle *h, int64_t n_rows, int32_t *in
   info_host[5] = nnv::kRowsPerTile;
   info_host[6] = h->shape.depth;
   info_host[7] = h->shape.n_classes;
+  info_host[8] = h->shape.precision;
   return NNV_OK;
 }
 

@@ -33,15 +33,23 @@ namespace nnv {
 // wpack = [hidden layers' groups][output layer's groups][biases, each layer
 // padded to 32*MT floats]
 // ---------------------------------------------------------------------------
+// f16x3 packing (NNV_PRECISION_F16X3): the same group size in bytes, holding
+// [lane][8 halves]: one group = the hi (or lo) f16 halves of one 16-wide k-step.
+//  layer 1   groups [mt][ks][hi|lo]       k-slot (lane>>5, e) <-> input (lane>>5)*bp + 8ks + e
+//  layer >=2 groups [mt][kt][s][hi|lo]    k-slot (lane>>5, e) <-> neuron 32kt + ((8s+e)&3)
+//                                         + 8((8s+e)>>2) + 4(lane>>5)  (accumulator register 8s+e)
+constexpr int kPrecF32 = 0;
+constexpr int kPrecF16x3 = 1;
 constexpr int kFragGroupFloats = 256;
 constexpr int kRowsPerTile = 32;  // batch rows per wave tile (MFMA N dim)
 
 struct PackedShape {
+  int32_t precision;    // kPrecF32 | kPrecF16x3
   int32_t depth;        // dense layers incl. output
   int32_t nhid;         // depth - 1
   int32_t n_in;         // dims[0]
   int32_t bp;           // ceil(n_in / 2): layer-1 K steps actually used
-  int32_t g1;           // ceil(bp / 4): layer-1 fragment groups per M-tile
+  int32_t g1;           // fp32: ceil(bp / 4) layer-1 groups per M-tile; f16x3: 2 * ceil(bp / 8)
   int32_t mt[3];        // hidden layers' M-tiles (width padded to 32)
   int32_t n_classes;    // dims[depth]
   int32_t mt_out;       // ceil(n_classes / 32)

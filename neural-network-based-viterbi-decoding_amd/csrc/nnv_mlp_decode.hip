@@ -31,6 +31,20 @@ namespace nnv {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// PREC = kPrecF32   : operands fp32, v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain).
+// PREC = kPrecF16x3 : every operand v is split into two halves, hi = f16(v),
+//   lo = f16(v - hi) (22 significant bits together), and each product block is
+//   three v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate): the
+//   "3xFP16" emulation of an fp32 GEMM on the 16-bit matrix pipe.  Error per
+//   product <= ~2^-21 relative, the same order as fp32 rounding itself
+//   (measured: max |out - fp64| 1.2e-6 vs 1.0e-6 for fp32).  On gfx950 the
+//   16-bit MFMA co-executes with VALU work while the fp32 MFMA does not, so
+//   this mode is bound by the tanh/argmax VALU work instead of the matrix pipe.
 
 // tanh(z) = 1 - 2 / (1 + e^{2z});  e^{2z} = 2^{z * 2 log2(e)}.
 // v_exp_f32 and v_rcp_f32 are 1-ulp hardware approximations; the absolute
@@ -55,6 +69,77 @@ __device__ __forceinline__ f32x4 load_a(const float *p) {
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// 8 fp32 values -> 8 f16 "hi" + 8 f16 "lo" (one MFMA k-step's B operand each),
+// round-to-nearest-even both times (v_cvt_pk_f16_f32).
+__device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 x = {v[2 * q], v[2 * q + 1]};
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(h, f32x2);
+    hi[q] = __builtin_bit_cast(unsigned, h);
+    lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+  }
+}
+
+// One 32-neuron tile of activations in the form the NEXT layer's MFMAs consume.
+//  fp32 : the accumulator itself (register r <-> k-step r of k-tile kt)
+//  f16x3: registers 8s..8s+7 converted to the hi/lo operands of k-step s = 0, 1
+template <int PREC>
+struct ActTile;
+template <>
+struct ActTile<kPrecF32> {
+  f32x16 v;
+  __device__ __forceinline__ void set(const f32x16 &a) { v = a; }
+};
+template <>
+struct ActTile<kPrecF16x3> {
+  u32x4 hi[2], lo[2];
+  __device__ __forceinline__ void set(const f32x16 &a) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = a[8 * s + e];
+      split8(t, hi[s], lo[s]);
+    }
+  }
+};
+
+// acc += W_tile^T * (KT activation tiles).  wbase points at this M-tile's
+// fragment groups (already offset by the lane): 1024 floats per k-tile in both
+// precisions (fp32: 4 groups of [lane][4 steps]; f16x3: 2 k-steps x {hi, lo} of
+// [lane][8 halves]).
+template <int PREC, int KT, typename Ptr>
+__device__ __forceinline__ f32x16 dense_tile(const ActTile<PREC> (&in)[KT], Ptr wbase, f32x16 acc) {
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    if constexpr (PREC == kPrecF32) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 a = load_a(wbase + (kt * 4 + q) * kFragGroupFloats);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(a[e], in[kt].v[4 * q + e], acc);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const u32x4 ahi = *reinterpret_cast<const u32x4 *>(wbase + ((kt * 2 + s) * 2 + 0) * kFragGroupFloats);
+        const u32x4 alo = *reinterpret_cast<const u32x4 *>(wbase + ((kt * 2 + s) * 2 + 1) * kFragGroupFloats);
+        acc = mfma16(alo, in[kt].hi[s], acc);  // small terms first
+        acc = mfma16(ahi, in[kt].lo[s], acc);
+        acc = mfma16(ahi, in[kt].hi[s], acc);
+      }
+    }
+  }
+  return acc;
 }
 
 // acc register r = 4q+e of a 32x32 tile holds neuron 8q + 4*(lane>>5) + e of
@@ -145,10 +230,15 @@ __device__ unsigned long long g_diag[16];
 #define NNV_STAMP(slot) do {} while (0)
 #endif
 
-template <int G1, int NHID, int MTA, int MTB, int MTC, int NT, bool WRITE_ACT>
+template <int PREC, int G1, int NHID, int MTA, int MTB, int MTC, int NT, bool WRITE_ACT>
 __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int W1F = MTA * G1 * kFragGroupFloats;
+  // layer 1: fp32 G1 groups of 4 steps (2 inputs each); f16x3 KS1 k-steps of 16 inputs
+  constexpr int KS1 = (G1 + 1) / 2;
+  constexpr int XN = PREC == kPrecF32 ? 4 * G1 : 8 * KS1;     // x values held per lane
+  constexpr int XG = XN / 4;
+  constexpr int L1_PER_MT = PREC == kPrecF32 ? G1 * kFragGroupFloats : KS1 * 2 * kFragGroupFloats;
+  constexpr int W1F = MTA * L1_PER_MT;
   constexpr int W2F = NHID >= 2 ? MTB * MTA * 4 * kFragGroupFloats : 0;
   constexpr int W3F = NHID >= 3 ? MTC * MTB * 4 * kFragGroupFloats : 0;
   constexpr int HIDF = W1F + W2F + W3F;
@@ -202,8 +292,8 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   int64_t tile = grab_tile();
 
   unsigned bit_err = 0, frame_err = 0;
-  float xr[4 * G1];
-  if (tile < p.n_tiles) load_x<G1>(p, tile, j, half, xr);
+  float xr[XN];
+  if (tile < p.n_tiles) load_x<XG>(p, tile, j, half, xr);
 #ifdef NNV_DIAG
   unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long diag_last = __builtin_amdgcn_s_memtime();
@@ -212,7 +302,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 
   while (tile < p.n_tiles) {
     const int64_t next_tile = grab_tile();
-    float xn[4 * G1];
+    float xn[XN];
     bool prefetched = false;
     // The packed weights in LDS never change, so LLVM would hoist every
     // fragment read out of this persistent loop (and spill them).  Making the
@@ -225,68 +315,71 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     int label = 0;
     if (p.labels && half == 0 && row < p.n_rows) label = p.labels[row];  // needed only in the epilogue
     NNV_STAMP(0);  // loop top / x wait
-    // ---------------- layer 1: K = n_in (bp steps of 2) -------------------
-    f32x16 ha[MTA];
+    // ---------------- layer 1: K = n_in --------------------------------------
+    ActTile<PREC> ha[MTA];
+    {
+      u32x4 xhi[KS1], xlo[KS1];
+      if constexpr (PREC == kPrecF16x3) {
 #pragma unroll
-    for (int mt = 0; mt < MTA; ++mt) {
-      f32x16 acc = init_acc(lds + B1OFF + 32 * mt, half);
-#pragma unroll
-      for (int g = 0; g < G1; ++g) {
-        const f32x4 a = load_a(lds + (mt * G1 + g) * kFragGroupFloats + lo);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = mfma32(a[e], xr[4 * g + e], acc);
+        for (int s = 0; s < KS1; ++s) split8(xr + 8 * s, xhi[s], xlo[s]);
       }
-      tanh16(acc);
-      ha[mt] = acc;
+#pragma unroll
+      for (int mt = 0; mt < MTA; ++mt) {
+        f32x16 acc = init_acc(lds + B1OFF + 32 * mt, half);
+        if constexpr (PREC == kPrecF32) {
+#pragma unroll
+          for (int g = 0; g < G1; ++g) {
+            const f32x4 a = load_a(lds + (mt * G1 + g) * kFragGroupFloats + lo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma32(a[e], xr[4 * g + e], acc);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < KS1; ++s) {
+            const float *wb = lds + mt * L1_PER_MT + s * 2 * kFragGroupFloats + lo;
+            const u32x4 ahi = *reinterpret_cast<const u32x4 *>(wb);
+            const u32x4 alo = *reinterpret_cast<const u32x4 *>(wb + kFragGroupFloats);
+            acc = mfma16(alo, xhi[s], acc);
+            acc = mfma16(ahi, xlo[s], acc);
+            acc = mfma16(ahi, xhi[s], acc);
+          }
+        }
+        tanh16(acc);
+        ha[mt].set(acc);
+      }
     }
     if (NHID == 1) {
-      if (next_tile < p.n_tiles) load_x<G1>(p, next_tile, j, half, xn);
+      if (next_tile < p.n_tiles) load_x<XG>(p, next_tile, j, half, xn);
       prefetched = true;
     }
 
     NNV_STAMP(1);  // layer 1
     // ---------------- layer 2 ---------------------------------------------
-    f32x16 hb[NHID >= 2 ? MTB : 1];
+    ActTile<PREC> hb[NHID >= 2 ? MTB : 1];
     if constexpr (NHID >= 2) {
 #pragma unroll
       for (int mt = 0; mt < MTB; ++mt) {
         f32x16 acc = init_acc(lds + B2OFF + 32 * mt, half);
-#pragma unroll
-        for (int kt = 0; kt < MTA; ++kt) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 a = load_a(lds + W1F + ((mt * MTA + kt) * 4 + q) * kFragGroupFloats + lo);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma32(a[e], ha[kt][4 * q + e], acc);
-          }
-        }
+        acc = dense_tile<PREC, MTA>(ha, lds + W1F + mt * MTA * 4 * kFragGroupFloats + lo, acc);
         tanh16(acc);
-        hb[mt] = acc;
+        hb[mt].set(acc);
       }
       if (!prefetched) {
-        if (next_tile < p.n_tiles) load_x<G1>(p, next_tile, j, half, xn);
+        if (next_tile < p.n_tiles) load_x<XG>(p, next_tile, j, half, xn);
         prefetched = true;
       }
     }
 
     NNV_STAMP(2);  // layer 2
     // ---------------- layer 3 ---------------------------------------------
-    f32x16 hc[NHID >= 3 ? MTC : 1];
+    ActTile<PREC> hc[NHID >= 3 ? MTC : 1];
     if constexpr (NHID >= 3) {
 #pragma unroll
       for (int mt = 0; mt < MTC; ++mt) {
         f32x16 acc = init_acc(lds + B3OFF + 32 * mt, half);
-#pragma unroll
-        for (int kt = 0; kt < MTB; ++kt) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 a = load_a(lds + W1F + W2F + ((mt * MTB + kt) * 4 + q) * kFragGroupFloats + lo);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma32(a[e], hb[kt][4 * q + e], acc);
-          }
-        }
+        acc = dense_tile<PREC, MTB>(hb, lds + W1F + W2F + mt * MTB * 4 * kFragGroupFloats + lo, acc);
         tanh16(acc);
-        hc[mt] = acc;
+        hc[mt].set(acc);
       }
     }
 
@@ -302,31 +395,10 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     for (int mt = 0; mt < p.mt_out; ++mt) {
       f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
       if (p.out_in_lds) {
-        const float *wl = lds + lds_out + mt * KT_OUT * 4 * kFragGroupFloats + lo;
-#pragma unroll
-        for (int kt = 0; kt < KT_OUT; ++kt) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 a = load_a(wl + (kt * 4 + q) * kFragGroupFloats);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              acc = mfma32(a[e], hlast[kt][4 * q + e], acc);
-            }
-          }
-        }
+        acc = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + mt * KT_OUT * 4 * kFragGroupFloats + lo, acc);
       } else {
-        const float *wg = p.wpack + HIDF + static_cast<int64_t>(mt) * KT_OUT * 4 * kFragGroupFloats + lo;
-#pragma unroll
-        for (int kt = 0; kt < KT_OUT; ++kt) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(wg + (kt * 4 + q) * kFragGroupFloats);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              acc = mfma32(a[e], hlast[kt][4 * q + e], acc);
-            }
-          }
-        }
+        acc = dense_tile<PREC, KT_OUT>(
+            hlast, p.wpack + HIDF + static_cast<int64_t>(mt) * KT_OUT * 4 * kFragGroupFloats + lo, acc);
       }
       const int cbase = 32 * mt + 4 * half;
       if constexpr (WRITE_ACT) {
@@ -453,35 +525,42 @@ namespace {
 using KernelFn = void (*)(const DecodeParams);
 
 struct KernelEntry {
-  int g1, nhid, mta, mtb, mtc, nt;
+  int prec, g1, nhid, mta, mtb, mtc, nt;
   bool act;
   KernelFn fn;
 };
 
-#define NNV_K(G1, NHID, A, B, C, NT, ACT) \
-  { G1, NHID, A, B, C, NT, ACT, mlp_decode_kernel<G1, NHID, A, B, C, NT, ACT> }
+#define NNV_K(P, G1, NHID, A, B, C, NT, ACT) \
+  { P, G1, NHID, A, B, C, NT, ACT, mlp_decode_kernel<P, G1, NHID, A, B, C, NT, ACT> }
 
 // The reference's networks: hidden widths are the first NHID of (128, 64, 32)
 // (src/fnn_viterbi.py:35-37) = M-tiles (4, 2, 1); n_in = 2b <= 24.
-#define NNV_FAMILY(G1)                                                       \
-  NNV_K(G1, 1, 4, 1, 1, 512, false), NNV_K(G1, 2, 4, 2, 1, 512, false),      \
-  NNV_K(G1, 3, 4, 2, 1, 512, false), NNV_K(G1, 1, 4, 1, 1, 1024, false),     \
-  NNV_K(G1, 2, 4, 2, 1, 1024, false), NNV_K(G1, 3, 4, 2, 1, 1024, false),    \
-  NNV_K(G1, 1, 4, 1, 1, 512, true), NNV_K(G1, 2, 4, 2, 1, 512, true),        \
-  NNV_K(G1, 3, 4, 2, 1, 512, true)
+#define NNV_FAMILY(P, G1)                                                          \
+  NNV_K(P, G1, 1, 4, 1, 1, 512, false), NNV_K(P, G1, 2, 4, 2, 1, 512, false),      \
+  NNV_K(P, G1, 3, 4, 2, 1, 512, false), NNV_K(P, G1, 1, 4, 1, 1, 1024, false),     \
+  NNV_K(P, G1, 2, 4, 2, 1, 1024, false), NNV_K(P, G1, 3, 4, 2, 1, 1024, false),    \
+  NNV_K(P, G1, 1, 4, 1, 1, 512, true), NNV_K(P, G1, 2, 4, 2, 1, 512, true),        \
+  NNV_K(P, G1, 3, 4, 2, 1, 512, true)
 
+const KernelEntry kKernels[] = {
+    NNV_FAMILY(kPrecF32, 1),   NNV_FAMILY(kPrecF32, 2),   NNV_FAMILY(kPrecF32, 3),
+    // f16x3: layer-1 k-steps = ceil(G1 / 2); G1 = 1, 2 share KS1 = 1 -> instantiate G1 = 2, 4
+    NNV_FAMILY(kPrecF16x3, 2), NNV_FAMILY(kPrecF16x3, 4),
+    // 3 waves per SIMD (<= 168 VGPRs): the f16x3 kernels need ~140
+    NNV_K(kPrecF16x3, 2, 1, 4, 1, 1, 768, false), NNV_K(kPrecF16x3, 2, 2, 4, 2, 1, 768, false),
+    NNV_K(kPrecF16x3, 2, 3, 4, 2, 1, 768, false), NNV_K(kPrecF16x3, 4, 1, 4, 1, 1, 768, false),
+    NNV_K(kPrecF16x3, 4, 2, 4, 2, 1, 768, false), NNV_K(kPrecF16x3, 4, 3, 4, 2, 1, 768, false),
 #ifdef NNV_DIAG
-const KernelEntry kKernels[] = {NNV_FAMILY(1), NNV_FAMILY(2), NNV_FAMILY(3), NNV_K(2, 3, 4, 2, 1, 256, false)};
-#else
-const KernelEntry kKernels[] = {NNV_FAMILY(1), NNV_FAMILY(2), NNV_FAMILY(3)};
+    NNV_K(kPrecF32, 2, 3, 4, 2, 1, 256, false), NNV_K(kPrecF16x3, 2, 3, 4, 2, 1, 256, false),
 #endif
+};
 
 const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act) {
   const int mta = s.mt[0];
   const int mtb = s.nhid >= 2 ? s.mt[1] : 1;
   const int mtc = s.nhid >= 3 ? s.mt[2] : 1;
   for (const KernelEntry &k : kKernels)
-    if (k.g1 == s.g1 && k.nhid == s.nhid && k.mta == mta && k.mtb == mtb &&
+    if (k.prec == s.precision && k.g1 == s.g1 && k.nhid == s.nhid && k.mta == mta && k.mtb == mtb &&
         k.mtc == mtc && k.nt == nt && k.act == act)
       return &k;
   return nullptr;
@@ -494,14 +573,17 @@ int pick_threads(const PackedShape &s) {
   static const int forced = [] {
     const char *e = getenv("NNV_THREADS");
     const int v = e ? atoi(e) : 0;
-    return (v == 256 || v == 512 || v == 1024) ? v : 0;
+    return (v == 256 || v == 512 || v == 768 || v == 1024) ? v : 0;
   }();
-  if (forced) return forced;
-  const KernelEntry *k = find_kernel(s, 1024, false);
-  if (!k) return 512;
-  hipFuncAttributes attr;
-  if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) return 512;
-  return attr.localSizeBytes == 0 ? 1024 : 512;
+  if (forced && find_kernel(s, forced, false)) return forced;
+  for (int nt : {1024, 768}) {  // most waves per SIMD whose instantiation does not spill
+    const KernelEntry *k = find_kernel(s, nt, false);
+    if (!k) continue;
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) continue;
+    if (attr.localSizeBytes == 0) return nt;
+  }
+  return 512;
 }
 
 }  // namespace

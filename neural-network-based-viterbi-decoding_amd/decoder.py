@@ -49,8 +49,14 @@ class PackedMLP:
     2..4 dense layers, the last one being the class layer.
     """
 
-    def __init__(self, weights: Sequence, biases: Sequence, device=None):
+    def __init__(self, weights: Sequence, biases: Sequence, device=None, precision: str = "f32"):
+        """``precision``: "f32" (exact fp32 MFMA chain, the default and the parity
+        reference) or "f16x3" (hi/lo f16 split operands on the 16-bit matrix pipe,
+        fp32 accumulate: ~2^-21 relative error per product, ~3x the throughput)."""
         _require_cuda()
+        if precision not in _cabi.NNV_PRECISION:
+            raise ValueError(f"precision must be one of {sorted(_cabi.NNV_PRECISION)}")
+        self.precision = precision
         self._lib = _cabi.load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()
                                    if device is None else torch.device(device).index or 0)
@@ -75,8 +81,9 @@ class PackedMLP:
             desc.b_host[i] = b.ctypes.data
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _cabi.check(self._lib.nnv_mlp_prepack(ctypes.byref(desc), ctypes.byref(handle)),
-                        "nnv_mlp_prepack")
+            _cabi.check(self._lib.nnv_mlp_prepack_ex(ctypes.byref(desc),
+                                                     _cabi.NNV_PRECISION[precision],
+                                                     ctypes.byref(handle)), "nnv_mlp_prepack_ex")
         self._handle = handle
 
     # -- lifetime ---------------------------------------------------------
@@ -186,12 +193,12 @@ class PackedMLP:
         return float(ms.value)
 
     def launch_info(self, n_rows: int) -> Dict[str, int]:
-        info = (ctypes.c_int32 * 8)()
+        info = (ctypes.c_int32 * 9)()
         with torch.cuda.device(self.device):
             _cabi.check(self._lib.nnv_mlp_launch_info(self._handle, int(n_rows), info),
                         "nnv_mlp_launch_info")
         keys = ("threads", "workgroups", "lds_bytes", "vgprs", "out_layer_in_lds",
-                "rows_per_wave_tile", "depth", "n_classes")
+                "rows_per_wave_tile", "depth", "n_classes", "precision")
         return dict(zip(keys, [int(v) for v in info]))
 
 

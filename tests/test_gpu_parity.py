@@ -25,6 +25,7 @@ from oracle import fnn_oracle as O
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
+PRECISIONS = ["f32", "f16x3"]   # exact fp32 MFMA chain | hi/lo f16 split operands, fp32 accumulate
 
 
 def _net(dims, seed, bias_scale=0.1):
@@ -54,14 +55,15 @@ def _hip_decode(net, x, labels=None, b=None, **kw):
 
 
 # ------------------------------------------------------------------ fixtures
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name,depth,b", [("b8_l3", 4, 8), ("b7_l3", 4, 7),
                                           ("b10_l2", 3, 10), ("b3_l3", 4, 3)])
-def test_golden_forward_fixtures(cuda_device, forward_golden, name, depth, b):
+def test_golden_forward_fixtures(cuda_device, forward_golden, name, depth, b, precision):
     fg = forward_golden
     Ws = [fg[f"{name}_W{i}"] for i in range(depth)]
     bs = [fg[f"{name}_b{i}"] for i in range(depth)]
     x, labels = fg[f"{name}_x"], fg[f"{name}_labels"]
-    net = PackedMLP(Ws, bs)
+    net = PackedMLP(Ws, bs, precision=precision)
     r = _hip_decode(net, x, labels, b)
     act = net.forward(torch.from_numpy(x).cuda()).cpu().numpy()
     bad = r["cls32"] != fg[f"{name}_cls"]
@@ -90,14 +92,15 @@ SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("dims,b", SHAPES)
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 4099])
-def test_decode_matches_oracle(cuda_device, dims, b, n):
+def test_decode_matches_oracle(cuda_device, dims, b, n, precision):
     Ws, bs = _net(dims, seed=b * 100 + len(dims))
     rng = np.random.RandomState(n)
     x = (rng.randn(n, dims[0]) * 1.2).astype(np.float32)
     labels = rng.randint(0, dims[-1], size=n).astype(np.int32)
-    net = PackedMLP(Ws, bs)
+    net = PackedMLP(Ws, bs, precision=precision)
     r = _hip_decode(net, x, labels, b)
     act = net.forward(torch.from_numpy(x).cuda()).cpu().numpy()
     _assert_parity(r["cls32"], act, x, Ws, bs, b)
@@ -108,17 +111,18 @@ def test_decode_matches_oracle(cuda_device, dims, b, n):
     net.close()
 
 
-def test_large_random_batch_flip_rate(cuda_device):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_large_random_batch_flip_rate(cuda_device, precision):
     """1e6 rows, config-3 row shape: report/assert the near-tie flip rate."""
     dims, b, n = [16, 128, 64, 32, 256], 8, 1_000_000
     Ws, bs = _net(dims, seed=5, bias_scale=0.0)
     rng = np.random.RandomState(1)
     x = rng.randn(n, 16).astype(np.float32)
-    net = PackedMLP(Ws, bs)
+    net = PackedMLP(Ws, bs, precision=precision)
     r = _hip_decode(net, x, None, b)
     ref = O.decode_c(x, Ws, bs, b, want_bits=False)
     diff = np.flatnonzero(r["cls32"] != ref["cls"])
-    assert len(diff) <= 20                       # fp32 summation-order ties: ~1e-6 of rows
+    assert len(diff) <= 20                       # summation-order / split-rounding ties: ~1e-6 of rows
     if len(diff):
         _assert_parity(r["cls32"][diff], None, x[diff], Ws, bs, b)
     net.close()
@@ -198,7 +202,8 @@ def test_tanh_accuracy_and_limits(cuda_device):
     net.close()
 
 
-def test_saturated_outputs_resolve_to_the_first_maximum(cuda_device):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_saturated_outputs_resolve_to_the_first_maximum(cuda_device, precision):
     """tanh saturates to exactly 1.0f for several classes: tf.argmax / np.argmax
     pick the first (src/fnn_viterbi.py:607,635)."""
     x = torch.zeros((40, 16), dtype=torch.float32, device="cuda")
@@ -209,7 +214,7 @@ def test_saturated_outputs_resolve_to_the_first_maximum(cuda_device):
         bo = np.full(256, -3.0, np.float32)
         bo[hot] = 30.0
         net = PackedMLP(Ws, [np.zeros(128, np.float32), np.zeros(64, np.float32),
-                             np.zeros(32, np.float32), bo])
+                             np.zeros(32, np.float32), bo], precision=precision)
         assert set(net.decode(x, tile_bits=8)["cls32"].cpu().tolist()) == {want}
         ref = O.decode_c(np.zeros((2, 16), np.float32), Ws, [np.zeros(128, np.float32),
                          np.zeros(64, np.float32), np.zeros(32, np.float32), bo], 8)
@@ -220,6 +225,13 @@ def test_saturated_outputs_resolve_to_the_first_maximum(cuda_device):
 def test_unsupported_network_fails_loudly(cuda_device):
     with pytest.raises(nnviterbi_amd.NNViterbiError):
         PackedMLP(*_net([16, 512, 256], 0))          # no kernel instantiation for this width
+    Ws, bs = _net([16, 128, 64, 32, 256], 0)
+    Ws[1][3, 5] = 70000.0                            # outside the f16 range: f16x3 must refuse, f32 must not
+    with pytest.raises(nnviterbi_amd.NNViterbiError):
+        PackedMLP(Ws, bs, precision="f16x3")
+    PackedMLP(Ws, bs, precision="f32").close()
+    with pytest.raises(ValueError):
+        PackedMLP(Ws, bs, precision="bf16")
     with pytest.raises(ValueError):
         PackedMLP([np.zeros((16, 256), np.float32)], [np.zeros(256, np.float32)])  # depth 1
 
@@ -267,12 +279,13 @@ def matched_filter_network(b, code):
     return Ws, [np.zeros(d, np.float32) for d in dims[1:]]
 
 
-def test_full_size_round_trip_and_counter_identities(cuda_device):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_round_trip_and_counter_identities(cuda_device, precision):
     """10 M blocks = 80 M rows (the benchmark's per-GPU workload)."""
     b, rows_per_block, n_blocks = 8, 8, 10_000_000
     n = n_blocks * rows_per_block
     Ws, bs = matched_filter_network(b, "133171")
-    net = PackedMLP(Ws, bs)
+    net = PackedMLP(Ws, bs, precision=precision)
     # (1) encode -> noiseless channel -> decode == identity, for every row
     x, lab = generate_awgn_blocks("133171", b, n, 0.0, seed=42, rows_per_block=rows_per_block)
     r = net.decode(x, labels=lab, tile_bits=b)

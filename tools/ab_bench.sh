@@ -1,11 +1,11 @@
 #!/bin/bash
-# Usage: tools/ab_bench.sh lib1.so lib2.so ...   (paths relative to the package dir)
+# Usage: [NNV_PREC=f32|f16x3] tools/ab_bench.sh lib1.so lib2.so ...   (paths relative to the package dir)
 # Runs bench.py (no CPU baseline) with each library and prints ms/step + roofline fraction.
 for lib in "$@"; do
-  NNV_LIB="$PWD/neural-network-based-viterbi-decoding_amd/$lib" python bench.py --no-cpu-baseline --steps 10 --warmup 2 > /tmp/ab.json 2>/dev/null
+  NNV_LIB="$PWD/neural-network-based-viterbi-decoding_amd/$lib" python bench.py --no-cpu-baseline --steps 10 --warmup 2 --precision ${NNV_PREC:-f32} > /tmp/ab.json 2>/dev/null
   python - "$lib" <<'PY'
 import json,sys
 d=json.load(open("/tmp/ab.json"))
-print(f"{sys.argv[1]:28s} ms/step {d['ms_per_step']:.3f}  kernel {d['roofline']['kernel_ms_per_launch']:.3f}  frac {d['roofline']['frac']:.4f}  vgprs {d['launch']['vgprs']}")
+print(f"{sys.argv[1]:24s} {d['dtype']:6s} ms/step {d['ms_per_step']:.3f}  kernel {d['roofline']['kernel_ms_per_launch']:.3f}  Mblocks/s {d['value']/1e6:.1f}  frac {d['roofline']['frac']:.4f}  threads {d['launch']['threads']} vgprs {d['launch']['vgprs']}")
 PY
 done

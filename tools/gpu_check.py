@@ -22,12 +22,12 @@ def make_net(dims, seed):
     return Ws, bs
 
 
-def check(dims, b, n, seed=0):
+def check(dims, b, n, seed=0, precision='f32'):
     Ws, bs = make_net(dims, seed)
     rng = np.random.RandomState(seed + 1)
     x = rng.randn(n, dims[0]).astype(np.float32)
     labels = rng.randint(0, dims[-1], size=n).astype(np.int32)
-    net = PackedMLP(Ws, bs)
+    net = PackedMLP(Ws, bs, precision=precision)
     xd = torch.from_numpy(x).cuda()
     ld = torch.from_numpy(labels).cuda()
     r = net.decode(xd, labels=ld, tile_bits=b, want_cls64=True, want_bits=True)
@@ -39,7 +39,7 @@ def check(dims, b, n, seed=0):
     mism = cls != ref["cls"]
     mism64 = cls != c64
     margin = O.top2_margin(o64)
-    print(f"dims={dims} b={b} n={n} info={net.launch_info(n)}")
+    print(f"[{precision}] dims={dims} b={b} n={n} info={net.launch_info(n)}")
     print(f"   mismatch vs C-oracle {mism.sum()}  vs fp64 {mism64.sum()}"
           f"  max fp64 margin on mismatches {margin[mism64].max() if mism64.any() else 0:.3e}")
     print(f"   max|act - fp64| {np.abs(act - o64).max():.3e}   C-oracle {np.abs(ref['act'] - o64).max():.3e}")
@@ -50,9 +50,9 @@ def check(dims, b, n, seed=0):
     net.close()
 
 
-def bench(dims, b, n, iters=5):
+def bench(dims, b, n, iters=5, precision='f32'):
     Ws, bs = make_net(dims, 3)
-    net = PackedMLP(Ws, bs)
+    net = PackedMLP(Ws, bs, precision=precision)
     x, labels = generate_awgn_blocks("133171" if b >= 6 else "57", b, n, 0.56, seed=1)
     if x.shape[1] != dims[0]:
         x = torch.randn(n, dims[0], device="cuda")
@@ -63,22 +63,24 @@ def bench(dims, b, n, iters=5):
         pass
     ms = net.decode_timed(x, labels, cls, cnt, iters, tile_bits=b) / iters
     flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
-    print(f"bench dims={dims} n={n}: {ms:.3f} ms/launch  {n / ms / 1e3:.1f} M rows/s  "
+    print(f"bench [{precision}] dims={dims} n={n}: {ms:.3f} ms/launch  {n / ms / 1e3:.1f} M rows/s  "
           f"{flop * n / ms / 1e9:.1f} TFLOP/s  info={net.launch_info(n)}")
     net.close()
 
 
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
-    check([16, 128, 64, 32, 256], 8, 100007)
-    check([14, 128, 64, 32, 128], 7, 50001)
-    check([20, 128, 64, 32, 1024], 10, 20011)
-    check([20, 128, 64, 1024], 10, 20000)
-    check([6, 128, 64, 32, 8], 3, 1000)
-    check([16, 128, 256], 8, 3333)
-    check([16, 100, 50, 20, 256], 8, 5000)
-    check([16, 128, 64, 32, 256], 8, 5)
-    bench([16, 128, 64, 32, 256], 8, 8 * 1000 * 1000)
-    bench([20, 128, 64, 32, 1024], 10, 2 * 1000 * 1000)
-    bench([20, 128, 64, 1024], 10, 2 * 1000 * 1000)
-    bench([14, 128, 64, 32, 128], 7, 4 * 1000 * 1000)
+    for prec in ("f32", "f16x3"):
+        check([16, 128, 64, 32, 256], 8, 100007, precision=prec)
+        check([14, 128, 64, 32, 128], 7, 50001, precision=prec)
+        check([20, 128, 64, 32, 1024], 10, 20011, precision=prec)
+        check([20, 128, 64, 1024], 10, 20000, precision=prec)
+        check([6, 128, 64, 32, 8], 3, 1000, precision=prec)
+        check([16, 128, 256], 8, 3333, precision=prec)
+        check([16, 100, 50, 20, 256], 8, 5000, precision=prec)
+        check([16, 128, 64, 32, 256], 8, 5, precision=prec)
+    for prec in ("f32", "f16x3"):
+        bench([16, 128, 64, 32, 256], 8, 80 * 1000 * 1000, precision=prec)
+        bench([20, 128, 64, 32, 1024], 10, 8 * 1000 * 1000, precision=prec)
+        bench([20, 128, 64, 1024], 10, 8 * 1000 * 1000, precision=prec)
+        bench([14, 128, 64, 32, 128], 7, 16 * 1000 * 1000, precision=prec)
