@@ -315,60 +315,68 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     int label = 0;
     if (p.labels && half == 0 && row < p.n_rows) label = p.labels[row];  // needed only in the epilogue
     NNV_STAMP(0);  // loop top / x wait
-    // ---------------- layer 1: K = n_in --------------------------------------
-    ActTile<PREC> ha[MTA];
-    {
-      u32x4 xhi[KS1], xlo[KS1];
-      if constexpr (PREC == kPrecF16x3) {
+    // ---------------- layer 1 (K = n_in), streamed into layer 2 ---------------
+    // Each 32-neuron tile of layer 1 is consumed by layer 2's accumulators as soon
+    // as it exists (k-tile by k-tile), so only ONE layer-1 tile is live at a time:
+    // ~48 fewer registers than holding the whole layer (4 waves/SIMD in f16x3).
+    u32x4 xhi[KS1], xlo[KS1];
+    if constexpr (PREC == kPrecF16x3) {
 #pragma unroll
-        for (int s = 0; s < KS1; ++s) split8(xr + 8 * s, xhi[s], xlo[s]);
-      }
-#pragma unroll
-      for (int mt = 0; mt < MTA; ++mt) {
-        f32x16 acc = init_acc(lds + B1OFF + 32 * mt, half);
-        if constexpr (PREC == kPrecF32) {
-#pragma unroll
-          for (int g = 0; g < G1; ++g) {
-            const f32x4 a = load_a(lds + (mt * G1 + g) * kFragGroupFloats + lo);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma32(a[e], xr[4 * g + e], acc);
-          }
-        } else {
-#pragma unroll
-          for (int s = 0; s < KS1; ++s) {
-            const float *wb = lds + mt * L1_PER_MT + s * 2 * kFragGroupFloats + lo;
-            const u32x4 ahi = *reinterpret_cast<const u32x4 *>(wb);
-            const u32x4 alo = *reinterpret_cast<const u32x4 *>(wb + kFragGroupFloats);
-            acc = mfma16(alo, xhi[s], acc);
-            acc = mfma16(ahi, xlo[s], acc);
-            acc = mfma16(ahi, xhi[s], acc);
-          }
-        }
-        tanh16(acc);
-        ha[mt].set(acc);
-      }
+      for (int s = 0; s < KS1; ++s) split8(xr + 8 * s, xhi[s], xlo[s]);
     }
-    if (NHID == 1) {
+    auto layer1_tile = [&](int mt) -> f32x16 {
+      f32x16 acc = init_acc(lds + B1OFF + 32 * mt, half);
+      if constexpr (PREC == kPrecF32) {
+#pragma unroll
+        for (int g = 0; g < G1; ++g) {
+          const f32x4 a = load_a(lds + (mt * G1 + g) * kFragGroupFloats + lo);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = mfma32(a[e], xr[4 * g + e], acc);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+          const float *wb = lds + mt * L1_PER_MT + s * 2 * kFragGroupFloats + lo;
+          const u32x4 ahi = *reinterpret_cast<const u32x4 *>(wb);
+          const u32x4 alo = *reinterpret_cast<const u32x4 *>(wb + kFragGroupFloats);
+          acc = mfma16(alo, xhi[s], acc);
+          acc = mfma16(ahi, xlo[s], acc);
+          acc = mfma16(ahi, xhi[s], acc);
+        }
+      }
+      tanh16(acc);
+      return acc;
+    };
+    ActTile<PREC> ha[NHID == 1 ? MTA : 1];
+    ActTile<PREC> hb[NHID >= 2 ? MTB : 1];
+    if constexpr (NHID == 1) {
+#pragma unroll
+      for (int mt = 0; mt < MTA; ++mt) ha[mt].set(layer1_tile(mt));
       if (next_tile < p.n_tiles) load_x<XG>(p, next_tile, j, half, xn);
       prefetched = true;
-    }
-
-    NNV_STAMP(1);  // layer 1
-    // ---------------- layer 2 ---------------------------------------------
-    ActTile<PREC> hb[NHID >= 2 ? MTB : 1];
-    if constexpr (NHID >= 2) {
+      NNV_STAMP(1);
+    } else {
+      f32x16 acc2[MTB];
+#pragma unroll
+      for (int mt = 0; mt < MTB; ++mt) acc2[mt] = init_acc(lds + B2OFF + 32 * mt, half);
+#pragma unroll
+      for (int kt = 0; kt < MTA; ++kt) {
+        ActTile<PREC> a[1];
+        a[0].set(layer1_tile(kt));
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt)
+          acc2[mt] = dense_tile<PREC, 1>(a, lds + W1F + (mt * MTA + kt) * 4 * kFragGroupFloats + lo, acc2[mt]);
+      }
+      NNV_STAMP(1);  // layer 1 + layer 2 MFMAs
+      if (next_tile < p.n_tiles) load_x<XG>(p, next_tile, j, half, xn);
+      prefetched = true;
 #pragma unroll
       for (int mt = 0; mt < MTB; ++mt) {
-        f32x16 acc = init_acc(lds + B2OFF + 32 * mt, half);
-        acc = dense_tile<PREC, MTA>(ha, lds + W1F + mt * MTA * 4 * kFragGroupFloats + lo, acc);
-        tanh16(acc);
-        hb[mt].set(acc);
-      }
-      if (!prefetched) {
-        if (next_tile < p.n_tiles) load_x<XG>(p, next_tile, j, half, xn);
-        prefetched = true;
+        tanh16(acc2[mt]);
+        hb[mt].set(acc2[mt]);
       }
     }
+    (void)prefetched;
 
     NNV_STAMP(2);  // layer 2
     // ---------------- layer 3 ---------------------------------------------
@@ -419,15 +427,33 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       if (((mt + 1) * 32) <= p.n_classes)
 #endif
       {
-        // per lane the class index grows with r, and mt grows outside: a
-        // strict > keeps the FIRST maximum of this lane's subset
+        // First maximum of this lane's 16 classes by a balanced tree (depth 4
+        // instead of a 16-long dependent chain): the class index grows with r, so
+        // "take the right operand only if strictly greater" keeps the first
+        // maximum at every node; then the same rule against the earlier M-tiles.
+        float v[16];
+        int ix[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float zc = __builtin_amdgcn_fmed3f(acc[r], -kTanhSat, kTanhSat);
-          const bool c = zc > best;
-          best = c ? zc : best;
-          bidx = c ? cbase + 8 * (r >> 2) + (r & 3) : bidx;
+        for (int r = 0; r < 16; ++r) v[r] = __builtin_amdgcn_fmed3f(acc[r], -kTanhSat, kTanhSat);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r0 = 2 * i, r1 = 2 * i + 1;
+          const bool c = v[r1] > v[r0];
+          ix[i] = c ? 8 * (r1 >> 2) + (r1 & 3) : 8 * (r0 >> 2) + (r0 & 3);
+          v[i] = c ? v[r1] : v[r0];
         }
+#pragma unroll
+        for (int w = 4; w >= 1; w >>= 1) {
+#pragma unroll
+          for (int i = 0; i < w; ++i) {
+            const bool c = v[2 * i + 1] > v[2 * i];
+            ix[i] = c ? ix[2 * i + 1] : ix[2 * i];
+            v[i] = c ? v[2 * i + 1] : v[2 * i];
+          }
+        }
+        const bool c = v[0] > best;
+        best = c ? v[0] : best;
+        bidx = c ? cbase + ix[0] : bidx;
       } else {  // last tile of a class count that is not a multiple of 32
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

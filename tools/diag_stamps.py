@@ -9,7 +9,7 @@ from nnviterbi_amd import fnn_viterbi as fv, _cabi
 from nnviterbi_amd.decoder import PackedMLP, generate_awgn_blocks
 cfg = fv.DecoderConfig(block_length=8)
 w, b = fv.initialize_weights(cfg, rng=np.random.RandomState(0))
-net = PackedMLP(*fv.weights_as_lists(w, b))
+net = PackedMLP(*fv.weights_as_lists(w, b), precision=os.environ.get('NNV_PREC', 'f32'))
 n = 16_000_000
 x, lab = generate_awgn_blocks("133171", 8, n, 0.56, 1)
 cls = torch.empty(n, dtype=torch.int32, device="cuda"); cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
@@ -25,7 +25,7 @@ info = net.launch_info(n)
 wps = info["threads"] // 256
 print(f"threads {info['threads']} ({wps} waves/SIMD)  {ms:.3f} ms for {n} rows  tiles by wave0: {tiles}")
 tot = sum(v[:6])
-mf = [0, 32, 128, 32, 128, 0]
+mf = [0, 32, 128, 32, 128, 0] if os.environ.get('NNV_PREC', 'f32') == 'f32' else [0, 6, 24, 6, 24, 0]
 for nm, c, m in zip(names, v[:6], mf):
     print(f"  {nm:22s} {c / tiles:9.0f} cyc/tile  ({100 * c / tot:5.1f} %)   ideal MFMA-only x waves: {m * 64 * wps}")
 print(f"  total {tot / tiles:.0f} cyc/tile/wave  -> per SIMD per tile {tot / tiles / wps:.0f}  (MFMA floor 20480)")
