@@ -114,8 +114,9 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X (no CPU fallback for the decode path)", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # == local_rank except in a 1-GPU rehearsal
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     # ---- network: seeded initialisation of the reference architecture ----
     cfg = fv.DecoderConfig(block_length=TILE_BITS, snr_db=SNR_DB)

@@ -167,6 +167,119 @@ class PackedMLP:
         _cabi.check(st, "nnv_mlp_decode_binned_f32")
         return {"cls32": cls32, "counters": counters}
 
+    def decode_host(self, x_host: np.ndarray, labels_host: Optional[np.ndarray] = None,
+                    tile_bits: Optional[int] = None, chunk_rows: int = 1 << 21,
+                    register_host: bool = True):
+        """The reference's call shape: a HOST ``test_set`` in, host predictions out
+        (``predictions_tensor.eval(feed_dict={x: test_set})``, src/fnn_viterbi.py:610).
+
+        The rows are streamed through the GPU in chunks on three HIP streams (H2D copy,
+        decode, D2H copy) with double-buffered device staging, from page-locked host memory
+        (the caller's arrays are registered in place when the runtime allows it, else staged
+        through pinned buffers), so PCIe transfers overlap the kernel.  Returns
+        ``(cls int64 [N], counters int64[4] | None)``."""
+        x_host = np.ascontiguousarray(x_host, dtype=np.float32)
+        if x_host.ndim != 2 or x_host.shape[1] != self.n_input:
+            raise ValueError(f"x must be float32 [N, {self.n_input}]")
+        n = x_host.shape[0]
+        b = self.tile_bits() if tile_bits is None else int(tile_bits)
+        lab_host = None
+        if labels_host is not None:
+            lab_host = np.ascontiguousarray(labels_host, dtype=np.int32)
+            if lab_host.shape != (n,):
+                raise ValueError("labels must be [N]")
+        out32 = np.empty(n, dtype=np.int32)
+        counters = torch.zeros(4, dtype=torch.int64, device=self.device) if lab_host is not None else None
+        if n == 0:
+            return out32.astype(np.int64), (None if counters is None else counters.cpu().numpy())
+        m = int(min(max(1, chunk_rows), n))
+        dev = self.device
+        rt = torch.cuda.cudart()
+        registered = []
+
+        def _register(a: np.ndarray) -> bool:
+            try:
+                if int(rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)) == 0:
+                    registered.append(a)
+                    return True
+            except Exception:
+                pass
+            return False
+
+        direct = register_host and _register(x_host) and _register(out32) and \
+            (lab_host is None or _register(lab_host))
+        try:
+            with torch.cuda.device(dev):
+                s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+                s_cmp = torch.cuda.current_stream(dev)
+                xd = [torch.empty((m, self.n_input), dtype=torch.float32, device=dev) for _ in range(2)]
+                cd = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(2)]
+                ld = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(2)] if lab_host is not None else None
+                if direct:
+                    xs, outs = torch.from_numpy(x_host), torch.from_numpy(out32)
+                    ls = torch.from_numpy(lab_host) if lab_host is not None else None
+                else:
+                    px = [torch.empty((m, self.n_input), dtype=torch.float32).pin_memory() for _ in range(2)]
+                    pc = [torch.empty(m, dtype=torch.int32).pin_memory() for _ in range(2)]
+                    pl = [torch.empty(m, dtype=torch.int32).pin_memory() for _ in range(2)] if lab_host is not None else None
+                ev_in = [None, None]
+                ev_cmp = [None, None]
+                ev_out = [None, None]
+                pending = [None, None]          # (lo, hi) of the chunk whose result sits in pc[k]
+                n_chunks = (n + m - 1) // m
+                for i in range(n_chunks):
+                    k = i & 1
+                    lo, hi = i * m, min(n, (i + 1) * m)
+                    cnt = hi - lo
+                    if not direct and pending[k] is not None:       # result of chunk i-2 back on the host?
+                        ev_out[k].synchronize()
+                        plo, phi = pending[k]
+                        out32[plo:phi] = pc[k][: phi - plo].numpy()
+                        pending[k] = None
+                    with torch.cuda.stream(s_in):
+                        if ev_cmp[k] is not None:
+                            s_in.wait_event(ev_cmp[k])               # device buffer k is free again
+                        if direct:
+                            xd[k][:cnt].copy_(xs[lo:hi], non_blocking=True)
+                            if ld is not None:
+                                ld[k][:cnt].copy_(ls[lo:hi], non_blocking=True)
+                        else:
+                            px[k][:cnt].copy_(torch.from_numpy(x_host[lo:hi]))
+                            xd[k][:cnt].copy_(px[k][:cnt], non_blocking=True)
+                            if ld is not None:
+                                pl[k][:cnt].copy_(torch.from_numpy(lab_host[lo:hi]))
+                                ld[k][:cnt].copy_(pl[k][:cnt], non_blocking=True)
+                        ev_in[k] = s_in.record_event()
+                    s_cmp.wait_event(ev_in[k])
+                    if ev_out[k] is not None:
+                        s_cmp.wait_event(ev_out[k])                  # cls buffer k has been drained
+                    st = self._lib.nnv_mlp_decode_f32(
+                        self._handle, _ptr(xd[k]), cnt, b, _ptr(ld[k]) if ld is not None else None,
+                        _ptr(cd[k]), None, None, _ptr(counters), _stream_ptr(dev))
+                    _cabi.check(st, "nnv_mlp_decode_f32")
+                    ev_cmp[k] = s_cmp.record_event()
+                    with torch.cuda.stream(s_out):
+                        s_out.wait_event(ev_cmp[k])
+                        if direct:
+                            outs[lo:hi].copy_(cd[k][:cnt], non_blocking=True)
+                        else:
+                            pc[k][:cnt].copy_(cd[k][:cnt], non_blocking=True)
+                            pending[k] = (lo, hi)
+                        ev_out[k] = s_out.record_event()
+                torch.cuda.synchronize(dev)
+                if not direct:
+                    for k in range(2):
+                        if pending[k] is not None:
+                            plo, phi = pending[k]
+                            out32[plo:phi] = pc[k][: phi - plo].numpy()
+        finally:
+            for a in registered:
+                try:
+                    rt.cudaHostUnregister(a.ctypes.data)
+                except Exception:
+                    pass
+        return out32.astype(np.int64), (None if counters is None else counters.cpu().numpy())
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """The tanh'd output layer [N, n_classes] (debug / parity; slow)."""
         self._check_x(x)

@@ -40,7 +40,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # NNV_DIST_BACKEND=gloo: rehearse the multi-rank path with several ranks on ONE GPU
+            backend = os.environ.get("NNV_DIST_BACKEND") or \
+                ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -57,7 +59,12 @@ def all_reduce_counters(counters: torch.Tensor, group=None) -> torch.Tensor:
     if counters.dtype != torch.int64:
         raise ValueError("counters must be int64")
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
+        if counters.is_cuda and dist.get_backend(group) == "gloo":
+            host = counters.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            counters.copy_(host)
+        else:
+            dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
     return counters
 
 
@@ -65,15 +72,15 @@ def max_over_ranks(value: float, device=None, group=None) -> float:
     """MAX all-reduce of a python float (timing)."""
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64,
-                     device=device if device is not None else "cpu")
+    on_host = device is None or dist.get_backend(group) == "gloo"
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if on_host else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
 
 def barrier(device=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        if device is not None and torch.device(device).type == "cuda":
+        if device is not None and torch.device(device).type == "cuda" and dist.get_backend() != "gloo":
             dist.barrier(device_ids=[torch.device(device).index])
         else:
             dist.barrier()

@@ -278,6 +278,9 @@ def predict(test_set, weights: Dict, biases: Dict, labels: Optional[np.ndarray] 
     Ws, bs = weights_as_lists(weights, biases)
     net = PackedMLP(Ws, bs)
     try:
+        if not isinstance(test_set, torch.Tensor):
+            # host arrays (the reference's call shape): pipelined PCIe transfers + decode
+            return net.decode_host(np.asarray(test_set), labels, tile_bits=tile_bits)
         xd = _to_device_input(test_set)
         ld = None
         if labels is not None:

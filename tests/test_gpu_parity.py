@@ -176,6 +176,30 @@ def test_misaligned_and_strided_inputs(cuda_device):
     net.close()
 
 
+@pytest.mark.parametrize("register_host", [True, False])
+def test_host_array_pipeline_equals_resident_decode(cuda_device, register_host):
+    """The reference's call shape (host test_set in, host predictions out): chunked,
+    three-stream H2D / decode / D2H pipeline, with and without in-place page-locking."""
+    dims, b, n = [16, 128, 64, 32, 256], 8, 10_007
+    Ws, bs = _net(dims, 11)
+    rng = np.random.RandomState(5)
+    x = rng.randn(n, 16).astype(np.float32)
+    labels = rng.randint(0, 256, n).astype(np.int32)
+    net = PackedMLP(Ws, bs)
+    want = _hip_decode(net, x, labels, b)
+    for chunk in (1000, 4096, 1 << 20):
+        cls, counters = net.decode_host(x, labels, b, chunk_rows=chunk, register_host=register_host)
+        assert cls.dtype == np.int64 and np.array_equal(cls, want["cls64"])
+        assert np.array_equal(counters, want["counters"])
+    cls, counters = net.decode_host(x[:0], None, b)
+    assert cls.shape == (0,) and counters is None
+    cls, counters = net.decode_host(x, None, b, chunk_rows=3000, register_host=register_host)
+    assert counters is None and np.array_equal(cls, want["cls64"])
+    with pytest.raises(ValueError):
+        net.decode_host(x[:, :8], None, b)
+    net.close()
+
+
 def _tanh_probe_net(z):
     """Network whose output layer is tanh(z) for chosen z: zero weights, z as the
     output bias.  32 values per probe."""
@@ -261,7 +285,7 @@ def test_generator_is_independent_of_sharding_and_rejects_short_tiles(cuda_devic
 
 
 # ------------------------------------------------------------------ full size (BASELINE configs[2])
-def matched_filter_network(b, code):
+def matched_filter_network(b, code, n_layers=3):
     """A hand-built network of the reference's architecture that decodes
     noiseless codewords exactly: the hidden layers pass the 2b soft bits through
     (tanh is ~linear for small arguments), the class layer correlates with every
@@ -270,13 +294,40 @@ def matched_filter_network(b, code):
     enc = fv.encode_133171_batch(cb) if code == "133171" else fv.encode_57_batch(cb)
     sym = np.where(enc == 1, 1.0, -1.0).astype(np.float32)        # [C, 2b]
     n = 2 * b
-    dims = [n, 128, 64, 32, 2 ** b]
-    Ws = [np.zeros((dims[i], dims[i + 1]), np.float32) for i in range(4)]
+    dims = [n] + [128, 64, 32][:n_layers] + [2 ** b]
+    Ws = [np.zeros((dims[i], dims[i + 1]), np.float32) for i in range(n_layers + 1)]
     Ws[0][np.arange(n), np.arange(n)] = 0.05
-    Ws[1][np.arange(n), np.arange(n)] = 1.0
-    Ws[2][np.arange(n), np.arange(n)] = 1.0
-    Ws[3][:n, :] = sym.T * 2.0
+    for l in range(1, n_layers):
+        Ws[l][np.arange(n), np.arange(n)] = 1.0
+    Ws[n_layers][:n, :] = sym.T * 2.0
     return Ws, [np.zeros(d, np.float32) for d in dims[1:]]
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("code,b,n_layers,block_len,n_blocks,snr_db", [
+    ("57", 10, 3, 20, 1_000, 2.0),         # BASELINE configs[0]: (7,5) block_len=20, 1k blocks, 3-layer
+    ("57", 10, 2, 100, 1_000_000, 4.0),    # BASELINE configs[1]: (7,5) block_len=100, 1M blocks @ 4 dB, 2-layer
+])
+def test_baseline_configs_0_and_1_at_full_size(cuda_device, precision, code, b, n_layers, block_len,
+                                               n_blocks, snr_db):
+    """Tiling rule: b = 10 divides both block lengths; the class layer (1024 classes) does not fit the
+    LDS and is streamed from L2.  Round trip at full size + a bounded oracle sample."""
+    rpb = block_len // b
+    n = n_blocks * rpb
+    Ws, bs = matched_filter_network(b, code, n_layers)
+    net = PackedMLP(Ws, bs, precision=precision)
+    assert net.launch_info(n)["out_layer_in_lds"] == 0
+    x, lab = generate_awgn_blocks(code, b, n, 0.0, seed=5, rows_per_block=rpb)
+    r = net.decode(x, labels=lab, tile_bits=b)
+    assert torch.equal(r["cls32"], lab) and r["counters"].cpu().tolist() == [0, 0, n * b, n]
+    x, lab = generate_awgn_blocks(code, b, n, O.sigma_from_snr_db(snr_db), seed=6, rows_per_block=rpb)
+    r = net.decode(x, labels=lab, tile_bits=b)
+    m = min(n, 20_000)
+    ref = O.decode_c(x[:m].cpu().numpy(), Ws, bs, b, labels=lab[:m].cpu().numpy(), want_bits=False)
+    assert (r["cls32"][:m].cpu().numpy() != ref["cls"]).sum() <= 1
+    c = r["counters"].cpu().numpy()
+    assert c[2] == n * b and c[3] == n and 0 < c[0] < 0.1 * c[2]
+    net.close()
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
