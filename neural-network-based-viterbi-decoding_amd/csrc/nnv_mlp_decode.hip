@@ -58,13 +58,7 @@ __device__ __forceinline__ float tanh_f32(float z) {
 }
 
 __device__ __forceinline__ f32x4 load_a(const float *p) {
-#ifdef NNV_ABLATE_LDSA  // timing experiments only: results are wrong
-  f32x4 v = {1.f, 2.f, 3.f, 4.f};
-  asm volatile("" : "+v"(v) : "v"(p));
-  return v;
-#else
   return *reinterpret_cast<const f32x4 *>(p);
-#endif
 }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -159,27 +153,9 @@ __device__ __forceinline__ f32x16 init_acc(const float *bias_tile, int half) {
   return acc;
 }
 
-// 16 tanh in stages of NNV_TANH_ILP independent values, so that one wave's
-// transcendental latencies overlap instead of forming one dependent chain.
-#ifndef NNV_TANH_ILP
-#define NNV_TANH_ILP 8
-#endif
 __device__ __forceinline__ void tanh16(f32x16 &acc) {
-#ifdef NNV_ABLATE_TANH  // timing experiments only: results are wrong
 #pragma unroll
-  for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(acc[r]));
-  return;
-#endif
-#pragma unroll
-  for (int r0 = 0; r0 < 16; r0 += NNV_TANH_ILP) {
-    float e[NNV_TANH_ILP];
-#pragma unroll
-    for (int i = 0; i < NNV_TANH_ILP; ++i) e[i] = __builtin_amdgcn_exp2f(acc[r0 + i] * 2.8853900817779268f);
-#pragma unroll
-    for (int i = 0; i < NNV_TANH_ILP; ++i) e[i] = __builtin_amdgcn_rcpf(1.0f + e[i]);
-#pragma unroll
-    for (int i = 0; i < NNV_TANH_ILP; ++i) acc[r0 + i] = __builtin_fmaf(-2.0f, e[i], 1.0f);
-  }
+  for (int r = 0; r < 16; ++r) acc[r] = tanh_f32(acc[r]);
 }
 
 // fp32 tanh returns exactly +-1.0f beyond |z| ~ 9.011 (1 - tanh z < 2^-25), for
@@ -418,15 +394,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
           }
         }
       }
-#ifdef NNV_ABLATE_ARGMAX  // timing experiments only: results are wrong
-#pragma unroll
-      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(acc[r]));
-      best = acc[0];
-      if (false)
-#else
-      if (((mt + 1) * 32) <= p.n_classes)
-#endif
-      {
+      if (((mt + 1) * 32) <= p.n_classes) {
         // First maximum of this lane's 16 classes by a balanced tree (depth 4
         // instead of a 16-long dependent chain): the class index grows with r, so
         // "take the right operand only if strictly greater" keeps the first
