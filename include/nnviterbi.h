@@ -173,6 +173,51 @@ int32_t nnv_awgn_generate_f32(int32_t code, int32_t tile_bits, int64_t n_rows,
                               uint64_t seed, float *x_dev, int32_t *labels_dev,
                               void *stream);
 
+/* ------------------------------------------------------------------------
+ * Wide networks (layer-at-a-time path): hidden widths beyond the register-
+ * chained kernel, e.g. the reference's sliding-window decoder
+ *   200 -> 500 -> 500 -> 500 -> 500 -> 2   src/fnn_viterbi_seq_predict.py:343-414
+ * One fp32-MFMA GEMM launch per layer (bias + tanh fused), activations in a
+ * caller-provided HBM workspace, a small head kernel for <= 32 classes.
+ * ------------------------------------------------------------------------ */
+#define NNV_WIDE_MAX_LAYERS 8
+
+typedef struct nnv_wide_desc {
+  int32_t depth;                         /* 2..NNV_WIDE_MAX_LAYERS dense layers */
+  int32_t dims[NNV_WIDE_MAX_LAYERS + 1]; /* dims[0] = row length, dims[depth] = n_classes */
+  const float *W_host[NNV_WIDE_MAX_LAYERS]; /* [dims[l]][dims[l+1]] row-major */
+  const float *b_host[NNV_WIDE_MAX_LAYERS];
+} nnv_wide_desc;
+
+typedef struct nnv_wide_handle nnv_wide_handle;
+
+/* Replaces build_network's variables (src/fnn_viterbi_seq_predict.py:343-414). */
+int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out);
+int32_t nnv_wide_free(nnv_wide_handle *h);
+
+/* Bytes of workspace needed to process `chunk_rows` rows at a time. */
+int64_t nnv_wide_workspace_bytes(const nnv_wide_handle *h, int64_t chunk_rows);
+
+/*
+ * Replaces  predictions = tf.argmax(pred, 1).eval({x: test_data})
+ * (src/fnn_viterbi_seq_predict.py:497,524,611) AND the Python loop that
+ * materialises test_data from the stream (:507-519, get_single_instance
+ * :293-336): row i of the input is the `dims[0]` floats starting at
+ * x_dev + i * row_stride.  row_stride == dims[0] is an ordinary [n_rows, dims[0]]
+ * matrix; row_stride == 2 with x_dev = the received stream is the sliding
+ * window (window i = coded[2i : 2i + window_length]).  x_dev must be 8-byte
+ * aligned and hold (n_rows - 1) * row_stride + dims[0] floats.
+ *  workspace_dev  device scratch, >= nnv_wide_workspace_bytes(h, 128) bytes;
+ *                 rows are processed in chunks that fit it
+ *  cls32_dev / cls64_dev  nullable [n_rows] decoded class (first maximum)
+ *  act_dev        nullable [n_rows][n_classes] tanh'd class layer (parity)
+ */
+int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev,
+                            int64_t n_rows, int64_t row_stride,
+                            void *workspace_dev, int64_t workspace_bytes,
+                            int32_t *cls32_dev, int64_t *cls64_dev,
+                            float *act_dev, void *stream);
+
 /*
  * Timing helper used by bench.py: launches nnv_mlp_decode_f32 `iters` times
  * back-to-back on `stream` between two HIP events recorded on that same

@@ -27,11 +27,24 @@ EXPORTED_SYMBOLS = (
     "nnv_mlp_prepack", "nnv_mlp_prepack_ex", "nnv_mlp_free", "nnv_mlp_decode_f32", "nnv_mlp_decode_binned_f32",
     "nnv_mlp_forward_f32", "nnv_awgn_generate_f32",
     "nnv_mlp_decode_f32_timed", "nnv_mlp_launch_info",
+    "nnv_wide_prepack", "nnv_wide_free", "nnv_wide_workspace_bytes", "nnv_wide_decode_f32",
 )
 
 
 class NNViterbiError(RuntimeError):
     """A C-ABI call failed, or the HIP library is not available."""
+
+
+NNV_WIDE_MAX_LAYERS = 8
+
+
+class WideDesc(ctypes.Structure):
+    _fields_ = [
+        ("depth", ctypes.c_int32),
+        ("dims", ctypes.c_int32 * (NNV_WIDE_MAX_LAYERS + 1)),
+        ("W_host", ctypes.c_void_p * NNV_WIDE_MAX_LAYERS),
+        ("b_host", ctypes.c_void_p * NNV_WIDE_MAX_LAYERS),
+    ]
 
 
 class MlpDesc(ctypes.Structure):
@@ -103,6 +116,16 @@ def load_library() -> ctypes.CDLL:
         c.c_void_p, c.c_void_p, c.c_int32, c.POINTER(c.c_float)]
     lib.nnv_mlp_launch_info.restype = c.c_int32
     lib.nnv_mlp_launch_info.argtypes = [c.c_void_p, c.c_int64, c.POINTER(c.c_int32)]
+    lib.nnv_wide_prepack.restype = c.c_int32
+    lib.nnv_wide_prepack.argtypes = [c.POINTER(WideDesc), c.POINTER(c.c_void_p)]
+    lib.nnv_wide_free.restype = c.c_int32
+    lib.nnv_wide_free.argtypes = [c.c_void_p]
+    lib.nnv_wide_workspace_bytes.restype = c.c_int64
+    lib.nnv_wide_workspace_bytes.argtypes = [c.c_void_p, c.c_int64]
+    lib.nnv_wide_decode_f32.restype = c.c_int32
+    lib.nnv_wide_decode_f32.argtypes = [
+        c.c_void_p, c.c_void_p, c.c_int64, c.c_int64, c.c_void_p, c.c_int64,
+        c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
     if lib.nnv_abi_version() != NNV_ABI_VERSION:
         raise NNViterbiError(
             f"ABI mismatch: library {lib.nnv_abi_version()} != binding {NNV_ABI_VERSION}")

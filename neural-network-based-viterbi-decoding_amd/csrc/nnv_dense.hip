@@ -1,0 +1,204 @@
+// Layer-at-a-time path for WIDE feed-forward decoders (hidden widths that do
+// not fit the register-chained kernel of nnv_mlp_decode.hip): one LDS-tiled
+// fp32-MFMA GEMM launch per dense layer with the bias add and tanh fused into
+// the epilogue, activations in HBM between layers, and a small head kernel for
+// a narrow class layer.
+//
+// First user: the reference's sliding-window decoder
+//   src/fnn_viterbi_seq_predict.py:293-336  window i = coded[2i : 2i+window)
+//   src/fnn_viterbi_seq_predict.py:343-414  200 -> 500 -> 500 -> 500 -> 500 -> 2, tanh everywhere
+//   src/fnn_viterbi_seq_predict.py:497,592-611  argmax over the 2 outputs = the decoded bit
+// Layer 1 gathers its rows straight from the single received stream
+// (row i starts at stream + i*row_stride), so the [N, window] matrix the
+// reference materialises in Python is never built.
+//
+// GEMM: C[rows, M] = tanh(A[rows, K] * W[K, M] + b), exact fp32
+// (v_mfma_f32_32x32x2_f32 = k-ordered fmaf chain), op order matmul, add, tanh
+// as in the reference.  128x128 block tile, BK = 32, 4 waves x (2x2) 32x32 MFMA
+// tiles, operands staged through LDS as [row][k] / [neuron][k] with a 36-float
+// row stride so that every ds_read_b128 / ds_write_b128 is conflict free; the
+// k index inside an 8-wide group is permuted (lane half h takes k0+4h..k0+4h+3)
+// so one b128 read feeds 4 MFMAs for both operands; next k-tile's global loads
+// are issued before the MFMAs of the current one.
+#include "nnv_internal.h"
+
+namespace nnv {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+constexpr int kBM = kDenseBM, kBN = kDenseBN, kBK = kDenseBK, kLdsStride = 36;
+
+__device__ __forceinline__ float dense_tanh_f32(float z) {
+  const float e = __builtin_amdgcn_exp2f(z * 2.8853900817779268f);
+  const float r = __builtin_amdgcn_rcpf(1.0f + e);
+  return __builtin_fmaf(-2.0f, r, 1.0f);
+}
+
+template <bool GATHER>
+__global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
+  __shared__ __attribute__((aligned(16))) float lds_a[kBM * kLdsStride];
+  __shared__ __attribute__((aligned(16))) float lds_w[kBN * kLdsStride];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t blk = blockIdx.x;
+  const int col_blk = static_cast<int>(blk % p.nblk_m);
+  const int64_t row_blk = blk / p.nblk_m;
+  const int64_t row0 = row_blk * kBM;
+  const int col0 = col_blk * kBN;
+
+  // global -> register staging: 128 rows x 32 k = 1024 float4, 4 per thread
+  const int ld_row = tid >> 3;       // 0..31 (+32 per pass)
+  const int ld_kq = (tid & 7) * 4;   // 0,4,..,28
+  f32x4 ra[4], rw[4];
+
+  auto load_tiles = [&](int kt) {
+    const int k = kt * kBK + ld_kq;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      int64_t r = row0 + ld_row + 32 * ps;
+      r = r < p.n_rows ? r : p.n_rows - 1;
+      const float *src = p.A + r * p.a_row_stride + k;
+      if (GATHER) {  // rows are only 8-byte aligned and may run past K: guarded 2-float loads
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k + 1 < p.K) {
+          const f32x2 t = *reinterpret_cast<const f32x2 *>(src);
+          v[0] = t[0];
+          v[1] = t[1];
+        } else if (k < p.K) {
+          v[0] = src[0];
+        }
+        if (k + 3 < p.K) {
+          const f32x2 t = *reinterpret_cast<const f32x2 *>(src + 2);
+          v[2] = t[0];
+          v[3] = t[1];
+        } else if (k + 2 < p.K) {
+          v[2] = src[2];
+        }
+        ra[ps] = v;
+      } else {
+        ra[ps] = *reinterpret_cast<const f32x4 *>(src);  // activations: [rows][Kpad], 16-byte aligned
+      }
+      rw[ps] = *reinterpret_cast<const f32x4 *>(p.Wt + static_cast<int64_t>(col0 + ld_row + 32 * ps) * p.Kpad + k);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      *reinterpret_cast<f32x4 *>(lds_a + (ld_row + 32 * ps) * kLdsStride + ld_kq) = ra[ps];
+      *reinterpret_cast<f32x4 *>(lds_w + (ld_row + 32 * ps) * kLdsStride + ld_kq) = rw[ps];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  const int nk = p.Kpad / kBK;
+  load_tiles(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // every wave is done reading the previous tile
+    store_tiles();
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[t] = *reinterpret_cast<const f32x4 *>(lds_a + (wr + 32 * t + li) * kLdsStride + 8 * g + 4 * lh);
+        fb[t] = *reinterpret_cast<const f32x4 *>(lds_w + (wc + 32 * t + li) * kLdsStride + 8 * g + 4 * lh);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // epilogue: + bias, tanh, store.  D: column (neuron) on the lane, rows in the registers.
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int col = col0 + wc + 32 * b + li;
+    const float bias = p.bias[col];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + wr + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < p.n_rows) {
+          float v = acc[a][b][r] + bias;
+          if (p.apply_tanh) v = dense_tanh_f32(v);
+          p.C[row * p.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// Narrow class layer (n_classes <= 32, e.g. the 2-way bit decision of the sliding-window
+// decoder): one half-wave per row, float4 reads of the row, per-class partial dot products,
+// xor-shuffle reduction, tanh, first-maximum argmax (src/fnn_viterbi_seq_predict.py:497).
+__global__ __launch_bounds__(256) void head_argmax_kernel(const HeadParams p) {
+  const int lane = threadIdx.x & 31;
+  const int64_t row = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 5;
+  const bool live = row < p.n_rows;
+  const float *a = p.A + (live ? row : 0) * p.lda;
+  float best = -__builtin_inff();
+  int bidx = 0;
+  for (int c = 0; c < p.n_classes; ++c) {
+    const float *w = p.Wt + static_cast<int64_t>(c) * p.Kpad;
+    float s = 0.f;
+    for (int k = lane * 4; k < p.Kpad; k += 128) {
+      const f32x4 av = *reinterpret_cast<const f32x4 *>(a + k);
+      const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + k);
+      s = __builtin_fmaf(av[0], wv[0], s);
+      s = __builtin_fmaf(av[1], wv[1], s);
+      s = __builtin_fmaf(av[2], wv[2], s);
+      s = __builtin_fmaf(av[3], wv[3], s);
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 32);
+    const float v = dense_tanh_f32(s + p.bias[c]);
+    if (p.act && live && lane == 0) p.act[row * p.n_classes + c] = v;
+    if (v > best) {
+      best = v;
+      bidx = c;
+    }
+  }
+  if (live && lane == 0) {
+    if (p.cls32) p.cls32[row] = bidx;
+    if (p.cls64) p.cls64[row] = bidx;
+  }
+}
+
+nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream) {
+  const int64_t blocks = p.nblk_rows * p.nblk_m;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return NNV_ERR_INVALID_ARGUMENT;
+  if (gather)
+    hipLaunchKernelGGL(dense_tanh_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL(dense_tanh_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+}
+
+nnv_status head_launch(const HeadParams &p, hipStream_t stream) {
+  const int64_t blocks = (p.n_rows * 32 + 255) / 256;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return NNV_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(head_argmax_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+}
+
+}  // namespace nnv

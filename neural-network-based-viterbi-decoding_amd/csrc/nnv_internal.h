@@ -103,6 +103,37 @@ nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
                          hipStream_t stream);
 int decode_kernel_vgprs(const PackedShape &s);
 
+// nnv_dense.hip: layer-at-a-time path for wide networks
+constexpr int kDenseBM = 128, kDenseBN = 128, kDenseBK = 32;
+struct DenseParams {
+  const float *A;        // activations [n_rows][a_row_stride] or, gathered, stream + row * a_row_stride
+  int64_t a_row_stride;  // floats between consecutive rows
+  int64_t n_rows;
+  int32_t K;             // valid inputs (gather mode zero-fills k >= K)
+  int32_t Kpad;          // multiple of 32; Wt rows have this length
+  const float *Wt;       // [Mpad][Kpad] fp32, zero padded
+  const float *bias;     // [Mpad]
+  float *C;              // [n_rows][ldc]
+  int64_t ldc;
+  int32_t nblk_m;        // Mpad / 128
+  int64_t nblk_rows;     // ceil(n_rows / 128)
+  int32_t apply_tanh;
+};
+struct HeadParams {
+  const float *A;        // [n_rows][lda]
+  int64_t lda;
+  int64_t n_rows;
+  int32_t Kpad;
+  int32_t n_classes;     // <= 32
+  const float *Wt;       // [n_classes][Kpad]
+  const float *bias;
+  int32_t *cls32;
+  int64_t *cls64;
+  float *act;            // nullable [n_rows][n_classes]
+};
+nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream);
+nnv_status head_launch(const HeadParams &p, hipStream_t stream);
+
 // nnv_generator.hip
 nnv_status generate_launch(int32_t code, int32_t tile_bits, int64_t n_rows,
                            int64_t first_row, int64_t rows_per_block,

@@ -1,0 +1,193 @@
+// C ABI of the layer-at-a-time path (nnv_wide_*): packing, chunking, launches.
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "nnv_internal.h"
+
+struct nnv_wide_handle {
+  int32_t depth;
+  int32_t dims[NNV_WIDE_MAX_LAYERS + 1];
+  int32_t kpad[NNV_WIDE_MAX_LAYERS];  // padded input width of layer l (multiple of 32)
+  int32_t mpad[NNV_WIDE_MAX_LAYERS];  // padded output width (multiple of 128; class layer: see head)
+  int32_t head;                       // 1: the class layer runs in head_argmax_kernel (<= 32 classes)
+  float *dev;                         // all packed weights and biases
+  int64_t w_off[NNV_WIDE_MAX_LAYERS], b_off[NNV_WIDE_MAX_LAYERS];
+  int32_t max_mpad;
+};
+
+namespace {
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// first-maximum argmax over the first n_classes entries of each row (class counts > 32)
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float *A, int64_t lda, int64_t n_rows,
+                                                         int n_classes, int32_t *cls32, int64_t *cls64,
+                                                         float *act) {
+  const int lane = threadIdx.x & 31;
+  const int64_t row = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 5;
+  if (row >= n_rows) return;
+  const float *a = A + row * lda;
+  float best = -__builtin_inff();
+  int bidx = 0x7fffffff;
+  for (int c = lane; c < n_classes; c += 32) {
+    const float v = a[c];
+    if (act) act[row * n_classes + c] = v;
+    if (v > best) {
+      best = v;
+      bidx = c;
+    }
+  }
+  for (int off = 16; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 32);
+    const int oi = __shfl_xor(bidx, off, 32);
+    if (ov > best || (ov == best && oi < bidx)) {
+      best = ov;
+      bidx = oi;
+    }
+  }
+  if (lane == 0) {
+    if (cls32) cls32[row] = bidx;
+    if (cls64) cls64[row] = bidx;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out) {
+  if (!net || !out) return NNV_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (net->depth < 2 || net->depth > NNV_WIDE_MAX_LAYERS) return NNV_ERR_UNSUPPORTED_SHAPE;
+  for (int l = 0; l <= net->depth; ++l)
+    if (net->dims[l] < 1 || net->dims[l] > 16384) return NNV_ERR_INVALID_ARGUMENT;
+  for (int l = 0; l < net->depth; ++l)
+    if (!net->W_host[l] || !net->b_host[l]) return NNV_ERR_INVALID_ARGUMENT;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+    return NNV_ERR_NO_DEVICE;
+  if (!strstr(prop.gcnArchName, "gfx950")) return NNV_ERR_NO_DEVICE;
+
+  nnv_wide_handle *h = new (std::nothrow) nnv_wide_handle;
+  if (!h) return NNV_ERR_OUT_OF_MEMORY;
+  memset(h, 0, sizeof(*h));
+  h->depth = net->depth;
+  for (int l = 0; l <= net->depth; ++l) h->dims[l] = net->dims[l];
+  h->head = net->dims[net->depth] <= 32 ? 1 : 0;
+  int64_t total = 0;
+  for (int l = 0; l < net->depth; ++l) {
+    const bool is_head = h->head && l == net->depth - 1;
+    // layer l reads the previous layer's padded output (or the raw rows for l = 0)
+    h->kpad[l] = l == 0 ? round_up(net->dims[0], nnv::kDenseBK) : h->mpad[l - 1];
+    h->mpad[l] = is_head ? net->dims[l + 1] : round_up(net->dims[l + 1], nnv::kDenseBN);
+    if (!is_head && h->mpad[l] > h->max_mpad) h->max_mpad = h->mpad[l];
+    h->w_off[l] = total;
+    total += static_cast<int64_t>(h->mpad[l]) * h->kpad[l];
+    h->b_off[l] = total;
+    total += round_up(h->mpad[l], 4);
+  }
+  std::vector<float> host(static_cast<size_t>(total), 0.f);
+  for (int l = 0; l < net->depth; ++l) {
+    const int K = net->dims[l], M = net->dims[l + 1];
+    float *wt = host.data() + h->w_off[l];
+    for (int m = 0; m < M; ++m)
+      for (int k = 0; k < K; ++k) wt[static_cast<size_t>(m) * h->kpad[l] + k] = net->W_host[l][static_cast<size_t>(k) * M + m];
+    for (int m = 0; m < M; ++m) host[h->b_off[l] + m] = net->b_host[l][m];
+  }
+  if (hipMalloc(reinterpret_cast<void **>(&h->dev), host.size() * sizeof(float)) != hipSuccess) {
+    delete h;
+    return NNV_ERR_OUT_OF_MEMORY;
+  }
+  if (hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(h->dev);
+    delete h;
+    return NNV_ERR_HIP;
+  }
+  *out = h;
+  return NNV_OK;
+}
+
+int32_t nnv_wide_free(nnv_wide_handle *h) {
+  if (!h) return NNV_OK;
+  const hipError_t e = hipFree(h->dev);
+  delete h;
+  return e == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+}
+
+int64_t nnv_wide_workspace_bytes(const nnv_wide_handle *h, int64_t chunk_rows) {
+  if (!h || chunk_rows < 1) return -1;
+  const int64_t rows = (chunk_rows + 127) / 128 * 128;
+  return 2 * rows * h->max_mpad * static_cast<int64_t>(sizeof(float));
+}
+
+int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev, int64_t n_rows,
+                            int64_t row_stride, void *workspace_dev, int64_t workspace_bytes,
+                            int32_t *cls32_dev, int64_t *cls64_dev, float *act_dev, void *stream) {
+  if (!h || n_rows < 0 || row_stride < 1) return NNV_ERR_INVALID_ARGUMENT;
+  if (n_rows == 0) return NNV_OK;
+  if (!x_dev || !workspace_dev) return NNV_ERR_INVALID_ARGUMENT;
+  if (reinterpret_cast<uintptr_t>(x_dev) % 8 != 0 || (row_stride % 2) != 0) return NNV_ERR_INVALID_ARGUMENT;
+  const int64_t per_row = 2LL * h->max_mpad * static_cast<int64_t>(sizeof(float));
+  int64_t chunk = workspace_bytes / per_row / 128 * 128;
+  if (chunk < 128) return NNV_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float *buf[2] = {static_cast<float *>(workspace_dev),
+                   static_cast<float *>(workspace_dev) + chunk * h->max_mpad};
+  const int last = h->depth - 1;
+  for (int64_t done = 0; done < n_rows; done += chunk) {
+    const int64_t rows = n_rows - done < chunk ? n_rows - done : chunk;
+    const float *in = x_dev + done * row_stride;
+    int64_t in_stride = row_stride;
+    int cur = 0;
+    for (int l = 0; l < h->depth; ++l) {
+      if (l == last && h->head) {
+        nnv::HeadParams hp;
+        hp.A = in;
+        hp.lda = in_stride;
+        hp.n_rows = rows;
+        hp.Kpad = h->kpad[l];
+        hp.n_classes = h->dims[h->depth];
+        hp.Wt = h->dev + h->w_off[l];
+        hp.bias = h->dev + h->b_off[l];
+        hp.cls32 = cls32_dev ? cls32_dev + done : nullptr;
+        hp.cls64 = cls64_dev ? cls64_dev + done : nullptr;
+        hp.act = act_dev ? act_dev + done * hp.n_classes : nullptr;
+        const nnv_status st = nnv::head_launch(hp, s);
+        if (st != NNV_OK) return st;
+        break;
+      }
+      nnv::DenseParams dp;
+      dp.A = in;
+      dp.a_row_stride = in_stride;
+      dp.n_rows = rows;
+      dp.K = h->dims[l];
+      dp.Kpad = h->kpad[l];
+      dp.Wt = h->dev + h->w_off[l];
+      dp.bias = h->dev + h->b_off[l];
+      dp.C = buf[cur];
+      dp.ldc = h->mpad[l];
+      dp.nblk_m = h->mpad[l] / nnv::kDenseBN;
+      dp.nblk_rows = (rows + nnv::kDenseBM - 1) / nnv::kDenseBM;
+      dp.apply_tanh = 1;
+      const nnv_status st = nnv::dense_launch(dp, l == 0, s);
+      if (st != NNV_OK) return st;
+      in = buf[cur];
+      in_stride = h->mpad[l];
+      cur ^= 1;
+      if (l == last) {  // wide class layer: argmax over the tanh'd row
+        const int64_t blocks = (rows * 32 + 255) / 256;
+        hipLaunchKernelGGL(row_argmax_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, in,
+                           in_stride, rows, h->dims[h->depth], cls32_dev ? cls32_dev + done : nullptr,
+                           cls64_dev ? cls64_dev + done : nullptr,
+                           act_dev ? act_dev + done * h->dims[h->depth] : nullptr);
+        if (hipGetLastError() != hipSuccess) return NNV_ERR_HIP;
+      }
+    }
+  }
+  return NNV_OK;
+}
+
+}  // extern "C"

@@ -315,6 +315,89 @@ class PackedMLP:
         return dict(zip(keys, [int(v) for v in info]))
 
 
+class WideMLP:
+    """Layer-at-a-time decoder for WIDE networks (C ABI ``nnv_wide_*``): one fused
+    GEMM+bias+tanh launch per layer, activations in an HBM workspace.
+
+    Built for the reference's sliding-window decoder (200 -> 500 x4 -> 2,
+    src/fnn_viterbi_seq_predict.py:343-414): ``decode_stream`` takes the received
+    stream itself and decodes window i = stream[2i : 2i + window] without ever
+    materialising the [N, window] matrix the reference builds in Python (:507-519)."""
+
+    def __init__(self, weights: Sequence, biases: Sequence, device=None, chunk_rows: int = 1 << 18):
+        _require_cuda()
+        self._lib = _cabi.load_library()
+        self.device = torch.device("cuda", torch.cuda.current_device()
+                                   if device is None else torch.device(device).index or 0)
+        Ws = [_as_host_f32(w) for w in weights]
+        bs = [_as_host_f32(b).reshape(-1) for b in biases]
+        if len(Ws) != len(bs) or not (2 <= len(Ws) <= _cabi.NNV_WIDE_MAX_LAYERS):
+            raise ValueError("need 2..8 dense layers with one bias vector each")
+        dims = [Ws[0].shape[0]]
+        for W, b in zip(Ws, bs):
+            if W.ndim != 2 or W.shape[0] != dims[-1] or b.shape[0] != W.shape[1]:
+                raise ValueError("inconsistent layer shapes")
+            dims.append(W.shape[1])
+        self.dims, self.n_input, self.n_classes = dims, dims[0], dims[-1]
+        desc = _cabi.WideDesc()
+        desc.depth = len(Ws)
+        for i, d in enumerate(dims):
+            desc.dims[i] = d
+        for i, (W, b) in enumerate(zip(Ws, bs)):
+            desc.W_host[i] = W.ctypes.data
+            desc.b_host[i] = b.ctypes.data
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _cabi.check(self._lib.nnv_wide_prepack(ctypes.byref(desc), ctypes.byref(handle)),
+                        "nnv_wide_prepack")
+        self._handle = handle
+        nbytes = int(self._lib.nnv_wide_workspace_bytes(handle, int(chunk_rows)))
+        self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def close(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            self._lib.nnv_wide_free(h)
+        self._workspace = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _run(self, x: torch.Tensor, n_rows: int, row_stride: int, want_act: bool, want_cls64: bool):
+        cls32 = torch.empty(n_rows, dtype=torch.int32, device=self.device)
+        cls64 = torch.empty(n_rows, dtype=torch.int64, device=self.device) if want_cls64 else None
+        act = torch.empty((n_rows, self.n_classes), dtype=torch.float32, device=self.device) if want_act else None
+        with torch.cuda.device(self.device):
+            st = self._lib.nnv_wide_decode_f32(
+                self._handle, _ptr(x), int(n_rows), int(row_stride), _ptr(self._workspace),
+                int(self._workspace.numel()), _ptr(cls32), _ptr(cls64), _ptr(act), _stream_ptr(self.device))
+        _cabi.check(st, "nnv_wide_decode_f32")
+        return {"cls32": cls32, "cls64": cls64, "act": act}
+
+    def decode(self, x: torch.Tensor, want_act: bool = False, want_cls64: bool = False):
+        """Rows of an ordinary [N, n_input] float32 CUDA matrix."""
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+                and x.shape[1] == self.n_input and x.is_contiguous()):
+            raise ValueError(f"x must be a contiguous float32 CUDA tensor [N, {self.n_input}]")
+        return self._run(x, x.shape[0], self.n_input, want_act, want_cls64)
+
+    def decode_stream(self, stream: torch.Tensor, n_windows: Optional[int] = None, stride: int = 2,
+                      want_act: bool = False, want_cls64: bool = False):
+        """Sliding window over a 1-D received stream: window i = stream[stride*i : stride*i + n_input]
+        (get_single_instance with offset = 2i, src/fnn_viterbi_seq_predict.py:293-336)."""
+        if not (isinstance(stream, torch.Tensor) and stream.is_cuda and stream.dtype == torch.float32
+                and stream.dim() == 1 and stream.is_contiguous()):
+            raise ValueError("stream must be a contiguous 1-D float32 CUDA tensor")
+        most = (stream.numel() - self.n_input) // stride + 1 if stream.numel() >= self.n_input else 0
+        n = most if n_windows is None else int(n_windows)
+        if n < 0 or n > most:
+            raise ValueError(f"the stream holds at most {most} windows")
+        return self._run(stream, n, stride, want_act, want_cls64)
+
+
 def generate_awgn_blocks(code: str, tile_bits: int, n_rows: int, sigma, seed: int,
                          first_row: int = 0, rows_per_block: int = 1, device=None,
                          want_labels: bool = True):

@@ -42,8 +42,9 @@ def _import_reference():
     sys.path.insert(0, REF_SRC)
     import fnn_viterbi as ref_fnn  # noqa
     import fnn_viterbi_mixed_snr as ref_mix  # noqa
+    import fnn_viterbi_seq_predict as ref_seq  # noqa
     sys.path.pop(0)
-    return ref_fnn, ref_mix
+    return ref_fnn, ref_mix, ref_seq
 
 
 def _capture(fn, *a, **k):
@@ -54,7 +55,7 @@ def _capture(fn, *a, **k):
 
 
 def main():
-    ref_fnn, ref_mix = _import_reference()
+    ref_fnn, ref_mix, ref_seq = _import_reference()
     arrays = {}
     meta = {}
 
@@ -214,6 +215,39 @@ def main():
         "dtypes": [str(a.dtype) for a in (m_tr, m_te, m_trl, m_rl, m_rs, m_cb)],
         "shapes": [list(a.shape) for a in (m_tr, m_te, m_trl, m_rl, m_rs, m_cb)],
     }
+
+    # ---- 7. sliding-window decoder, numpy half (src/fnn_viterbi_seq_predict.py) ----
+    sc = ref_seq.SequentialDecoderConfig()
+    meta["seq_default_config"] = {
+        "total_training_instances": int(sc.total_training_instances),
+        "total_test_instances": int(sc.total_test_instances),
+        "total_train_length_coded": int(sc.total_train_length_coded),
+        "n_input": int(sc.n_input), "n_output": int(sc.n_output),
+        "snr_db_vec": [int(v) for v in sc.snr_db_vec],
+        "sigma_vec": [float(v) for v in sc.sigma_vec],
+        "test_snr_index": int(sc.test_snr_index),
+    }
+    small = ref_seq.SequentialDecoderConfig(total_train_length_info=70, total_test_length_info=90,
+                                            window_length=20, snr_db_range=(0, 4), test_snr_index=2)
+    meta["seq_small_config"] = {"total_training_instances": int(small.total_training_instances),
+                                "total_test_instances": int(small.total_test_instances)}
+    np.random.seed(31)
+    tr_info, tr_coded = ref_seq.generate_training_data(70, 1, small.sigma_vec)
+    te_info, te_coded = ref_seq.generate_test_data(90, 1, small.sigma_vec, 2)
+    arrays["seq_train_info"], arrays["seq_train_coded"] = tr_info, tr_coded
+    arrays["seq_test_info"], arrays["seq_test_coded"] = te_info, te_coded
+    meta["seq_dtypes"] = [str(a.dtype) for a in (tr_info, tr_coded, te_info, te_coded)]
+    inst_x, inst_y = [], []
+    for off in (0, 2, 36, 2 * (small.total_test_instances - 1)):
+        bx, by = ref_seq.get_single_instance(20, te_coded, te_info, off)
+        inst_x.append(bx)
+        inst_y.append(by)
+    arrays["seq_instance_x"] = np.stack(inst_x)
+    arrays["seq_instance_y"] = np.stack(inst_y)
+    meta["seq_instance_offsets"] = [0, 2, 36, 2 * (small.total_test_instances - 1)]
+    meta["seq_instance_dtypes"] = [str(inst_x[0].dtype), str(inst_y[0].dtype)]
+    np.random.seed(32)
+    arrays["seq_info_seq_seed32"] = ref_seq.generate_info_sequence(12)
 
     np.savez_compressed(os.path.join(HERE, "reference_numpy_half.npz"), **arrays)
     with open(os.path.join(HERE, "reference_numpy_half.json"), "w") as f:

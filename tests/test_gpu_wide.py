@@ -1,0 +1,118 @@
+"""Layer-at-a-time path (nnv_wide_*) and the sliding-window decoder on the GPU, against the oracle.
+Same stated tolerance as the register-chained kernel: outputs within 1e-5 of the float64
+restatement, classes may differ only on float64 near-ties (margin < 1e-5)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import nnviterbi_amd  # noqa: F401
+from nnviterbi_amd import fnn_viterbi as fv
+from nnviterbi_amd import fnn_viterbi_seq_predict as sq
+from nnviterbi_amd.decoder import WideMLP
+from oracle import fnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _net(dims, seed, bias_scale=0.1):
+    rng = np.random.RandomState(seed)
+    Ws = [fv.truncated_normal((dims[i], dims[i + 1]), np.sqrt(2.0 / dims[i]), rng) for i in range(len(dims) - 1)]
+    bs = [(rng.randn(dims[i + 1]) * bias_scale).astype(np.float32) for i in range(len(dims) - 1)]
+    return Ws, bs
+
+
+def _check(cls, act, x, Ws, bs):
+    c64, _, o64 = O.decode(x, Ws, bs, 1, np.float64)
+    assert np.abs(act - o64).max() < TOL
+    bad = cls != c64
+    assert not bad.any() or O.top2_margin(o64)[bad].max() < TOL
+
+
+def _stream(n_windows, window, seed):
+    rng = np.random.RandomState(seed)
+    n = 2 * (n_windows - 1) + window
+    return np.trunc(rng.choice([-1.0, 1.0], n) + 0.8 * rng.randn(n)).astype(np.float32)   # int-valued, like F12
+
+
+@pytest.mark.parametrize("n", [1, 127, 128, 129, 5000])
+def test_sliding_window_decoder_matches_oracle(cuda_device, n):
+    """Reference shape 200 -> 500 -> 500 -> 500 -> 500 -> 2 (src/fnn_viterbi_seq_predict.py:343-414)."""
+    dims = [200, 500, 500, 500, 500, 2]
+    Ws, bs = _net(dims, 3)
+    net = WideMLP(Ws, bs, chunk_rows=1024)            # several chunks at n = 5000
+    s = _stream(n, 200, n)
+    r = net.decode_stream(torch.from_numpy(s).cuda(), n, want_act=True, want_cls64=True)
+    x = np.ascontiguousarray(np.lib.stride_tricks.sliding_window_view(s, 200)[::2][:n])
+    cls, act = r["cls32"].cpu().numpy(), r["act"].cpu().numpy()
+    _check(cls, act, x, Ws, bs)
+    assert np.array_equal(r["cls64"].cpu().numpy(), cls.astype(np.int64))
+    ref = O.decode_c(x, Ws, bs, 1, want_bits=False)
+    assert (ref["cls"] != cls).sum() <= max(1, n // 1000)
+    r2 = net.decode(torch.from_numpy(x.copy()).cuda(), want_act=True)   # the materialised matrix
+    assert torch.equal(r2["cls32"], r["cls32"]) and torch.equal(r2["act"], r["act"])
+    net.close()
+
+
+@pytest.mark.parametrize("dims", [[14, 300, 70, 128], [16, 256, 128, 64, 256], [20, 64, 2], [30, 129, 33]])
+def test_wide_path_generic_shapes(cuda_device, dims):
+    Ws, bs = _net(dims, len(dims))
+    net = WideMLP(Ws, bs)
+    x = np.random.RandomState(1).randn(777, dims[0]).astype(np.float32)
+    r = net.decode(torch.from_numpy(x).cuda(), want_act=True)
+    _check(r["cls32"].cpu().numpy(), r["act"].cpu().numpy(), x, Ws, bs)
+    net.close()
+
+
+def test_wide_path_argument_errors(cuda_device):
+    Ws, bs = _net([200, 500, 2], 0)
+    net = WideMLP(Ws, bs)
+    s = torch.from_numpy(_stream(10, 200, 0)).cuda()
+    with pytest.raises(ValueError):
+        net.decode_stream(s, 11)                       # more windows than the stream holds
+    with pytest.raises(ValueError):
+        net.decode_stream(s.cpu(), 5)                  # host tensor
+    with pytest.raises(ValueError):
+        net.decode(torch.zeros((4, 100), device="cuda"))
+    assert net.decode_stream(s, 0)["cls32"].numel() == 0
+    with pytest.raises(ValueError):
+        WideMLP([np.zeros((8, 2), np.float32)], [np.zeros(2, np.float32)])   # depth 1
+    net.close()
+
+
+def test_train_and_evaluate_end_to_end(cuda_device, tmp_path):
+    """Tiny configuration: trains (PyTorch), saves, decodes the test stream on the GPU,
+    and the reload path reproduces the predictions."""
+    path = str(tmp_path / "seq_predict_model")
+    cfg = sq.SequentialDecoderConfig(total_train_length_info=6000, total_test_length_info=3000,
+                                     window_length=40, n_hidden_1=64, n_hidden_2=64, n_hidden_3=64,
+                                     n_hidden_4=64, learning_rate=0.002, training_epochs=12, batch_size=100,
+                                     snr_db_range=(4, 8), test_snr_index=2, model_save_path=path)
+    np.random.seed(0)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = sq.train_and_evaluate(cfg)
+    text = buf.getvalue()
+    assert "Epoch: 0001 | cost = " in text and "Optimization Finished!" in text
+    assert f"Model saved to {path}" in text and "Test Error Rate: " in text
+    costs = [float(l.split("=")[1]) for l in text.splitlines() if l.startswith("Epoch: ")]
+    assert len(costs) == 12 and costs[-1] < costs[0]   # the optimiser works (whether this decoder
+    assert 0.0 <= out["error_rate"] <= 1.0             # generalises is the reference's own matter)
+    Ws, bs = sq.weights_as_lists(out["weights"], out["biases"])
+    n = cfg.total_test_instances
+    x = sq.extract_windows(40, out["test_coded"], 0, n)
+    c64, _, o64 = O.decode(x, Ws, bs, 1, np.float64)
+    bad = out["predictions"] != c64
+    assert not bad.any() or O.top2_margin(o64)[bad].max() < TOL
+    act, w2, b2 = sq.build_network(x[:50], cfg, out["weights"], out["biases"])
+    assert np.abs(act - o64[:50]).max() < TOL
+    # reload: same test stream (same seed), same predictions
+    cfg.test_old_model, cfg.model_load_path = True, path
+    np.random.seed(0)
+    with contextlib.redirect_stdout(io.StringIO()) as b2:
+        again = sq.train_and_evaluate(cfg)
+    assert f"Model loaded from {path}" in b2.getvalue()
+    assert np.array_equal(again["predictions"], out["predictions"])

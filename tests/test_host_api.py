@@ -254,3 +254,55 @@ def test_trainer_reduces_the_loss_on_cpu():
     costs = [float(line.split("=")[1]) for line in text.strip().splitlines()]
     assert len(costs) == 3 and costs[-1] < costs[0]
     assert text.startswith("Epoch: 0001 | cost = ")
+
+
+# ---------------------------------------------------------------- sliding-window decoder, numpy half
+def test_seq_predict_config_and_streams_match_reference(golden):
+    from nnviterbi_amd import fnn_viterbi_seq_predict as sq
+    g, meta = golden
+    c = sq.SequentialDecoderConfig()
+    d = meta["seq_default_config"]
+    assert c.total_training_instances == d["total_training_instances"] == 1000000
+    assert c.total_test_instances == d["total_test_instances"]
+    assert c.total_train_length_coded == d["total_train_length_coded"]
+    assert (c.n_input, c.n_output, c.test_snr_index) == (d["n_input"], d["n_output"], d["test_snr_index"])
+    assert c.snr_db_vec.tolist() == d["snr_db_vec"] and np.array_equal(c.sigma_vec, np.array(d["sigma_vec"]))
+    small = sq.SequentialDecoderConfig(total_train_length_info=70, total_test_length_info=90,
+                                       window_length=20, snr_db_range=(0, 4), test_snr_index=2)
+    assert small.total_training_instances == meta["seq_small_config"]["total_training_instances"]
+    assert small.total_test_instances == meta["seq_small_config"]["total_test_instances"]
+    np.random.seed(31)
+    tr_info, tr_coded = sq.generate_training_data(70, 1, small.sigma_vec)
+    te_info, te_coded = sq.generate_test_data(90, 1, small.sigma_vec, 2)
+    assert [str(a.dtype) for a in (tr_info, tr_coded, te_info, te_coded)] == meta["seq_dtypes"]
+    assert np.array_equal(tr_info, g["seq_train_info"]) and np.array_equal(tr_coded, g["seq_train_coded"])
+    assert np.array_equal(te_info, g["seq_test_info"]) and np.array_equal(te_coded, g["seq_test_coded"])
+    assert te_coded.dtype == np.int32            # soft values truncated toward zero
+    for off, wx, wy in zip(meta["seq_instance_offsets"], g["seq_instance_x"], g["seq_instance_y"]):
+        bx, by = sq.get_single_instance(20, te_coded, te_info, off)
+        assert str(bx.dtype) == meta["seq_instance_dtypes"][0] and by.dtype == np.float32
+        assert np.array_equal(bx, wx) and np.array_equal(by, wy)
+    win = sq.extract_windows(20, te_coded, 0, small.total_test_instances)
+    assert win.shape == (small.total_test_instances, 20) and win.dtype == np.float32
+    for i in (0, 1, 17, small.total_test_instances - 1):
+        assert np.array_equal(win[i], sq.get_single_instance(20, te_coded, te_info, 2 * i)[0])
+    np.random.seed(32)
+    assert np.array_equal(sq.generate_info_sequence(12), g["seq_info_seq_seed32"])
+
+
+def test_seq_predict_weights_and_checkpoint(tmp_path):
+    from nnviterbi_amd import fnn_viterbi_seq_predict as sq
+    cfg = sq.SequentialDecoderConfig(window_length=20, n_hidden_1=48, n_hidden_2=40, n_hidden_3=36, n_hidden_4=33)
+    w, b = sq.initialize_weights(cfg, rng=np.random.RandomState(0))
+    assert [w[k].shape for k in ("h1", "h2", "h3", "h4", "out")] == [(20, 48), (48, 40), (40, 36), (36, 33), (33, 2)]
+    assert all(not v.any() for v in b.values())
+    p = sq.save_model(str(tmp_path / "seq_predict_model"), w, b)
+    assert sorted(np.load(p).files) == sorted(["weights_h1", "weights_h2", "weights_h3", "weights_h4",
+                                               "weights_out", "bias_h1", "bias_h2", "bias_h3", "bias_h4",
+                                               "bias_out"])
+    w2, b2 = sq.load_model(str(tmp_path / "seq_predict_model"))
+    assert all(np.array_equal(w[k], w2[k]) for k in w) and all(np.array_equal(b[k], b2[k]) for k in b)
+    cfg.test_old_model = True
+    with pytest.raises(RuntimeError):
+        with contextlib.redirect_stdout(io.StringIO()):
+            sq.train_and_evaluate(cfg)                # no model_load_path: nothing to evaluate
