@@ -45,9 +45,17 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
+  // XCD-aware block -> tile map.  Blocks b and b+8 are dispatched to the same XCD (its own L2),
+  // in order.  The nblk_m column blocks of one row block read the same A rows, so they are
+  // given consecutive slots of ONE XCD: the A k-slabs are then fetched once into that L2 and
+  // hit by the other column blocks, instead of being fetched by four different L2s.
+  // (A placement guess can only cost speed: every block computes a fixed, disjoint tile.)
   const int64_t blk = blockIdx.x;
-  const int col_blk = static_cast<int>(blk % p.nblk_m);
-  const int64_t row_blk = blk / p.nblk_m;
+  const int xcd = static_cast<int>(blk & 7);
+  const int64_t slot = blk >> 3;
+  const int col_blk = static_cast<int>(slot % p.nblk_m);
+  const int64_t row_blk = (slot / p.nblk_m) * 8 + xcd;
+  if (row_blk >= p.nblk_rows) return;  // grid is padded to a multiple of 8 row blocks
   const int64_t row0 = row_blk * kBM;
   const int col0 = col_blk * kBN;
 
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256) void head_argmax_kernel(const HeadParams p) {
 }
 
 nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream) {
-  const int64_t blocks = p.nblk_rows * p.nblk_m;
+  const int64_t blocks = (p.nblk_rows + 7) / 8 * 8 * p.nblk_m;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return NNV_ERR_INVALID_ARGUMENT;
   if (gather)
     hipLaunchKernelGGL(dense_tanh_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
