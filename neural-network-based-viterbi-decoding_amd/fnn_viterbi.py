@@ -256,15 +256,30 @@ def _to_device_input(x):
     return t.to(device="cuda", dtype=torch.float32).contiguous()
 
 
+def _open_decoder(Ws, bs):
+    """The register-chained kernel when it has an instantiation for this network (the
+    reference's hidden widths), else the layer-at-a-time HIP path, which takes any widths.
+    Both run on the GPU; there is no CPU path."""
+    from ._cabi import NNViterbiError
+    from .decoder import PackedMLP, WideMLP
+    try:
+        return PackedMLP(Ws, bs), False
+    except NNViterbiError as e:
+        if "unsupported network shape" not in str(e):
+            raise
+        return WideMLP(Ws, bs), True
+
+
 def multilayer_perceptron(x, weights: Dict, biases: Dict) -> np.ndarray:
     """tanh(...tanh(x@h1+b1)...@out+bout): the tanh'd class layer [N, n_classes]
     (src/fnn_viterbi.py:471-510), computed by the HIP kernel's debug output
     path.  Returns a numpy array (the reference returns a graph tensor)."""
-    from .decoder import PackedMLP
     Ws, bs = weights_as_lists(weights, biases)
-    net = PackedMLP(Ws, bs)
+    net, wide = _open_decoder(Ws, bs)
     try:
-        return net.forward(_to_device_input(x)).cpu().numpy()
+        xd = _to_device_input(x)
+        out = net.decode(xd, want_act=True)["act"] if wide else net.forward(xd)
+        return out.cpu().numpy()
     finally:
         net.close()
 
@@ -274,10 +289,18 @@ def predict(test_set, weights: Dict, biases: Dict, labels: Optional[np.ndarray] 
     """``tf.argmax(pred, 1).eval({x: test_set})`` (src/fnn_viterbi.py:606-610)
     on the GPU.  Returns (predictions int64 [N], counters int64[4] or None)."""
     import torch
-    from .decoder import PackedMLP
     Ws, bs = weights_as_lists(weights, biases)
-    net = PackedMLP(Ws, bs)
+    net, wide = _open_decoder(Ws, bs)
     try:
+        if wide:   # hidden widths outside the fused kernel's instantiations: layer-at-a-time path
+            cls = net.decode(_to_device_input(test_set), want_cls64=True)["cls64"].cpu().numpy()
+            counters = None
+            if labels is not None:
+                b = int(tile_bits) if tile_bits is not None else max(1, int(np.ceil(np.log2(Ws[-1].shape[1]))))
+                diff = cls ^ np.asarray(labels).astype(np.int64)
+                counters = np.array([int(_popcount(diff).sum()), int((diff != 0).sum()),
+                                     len(cls) * b, len(cls)], dtype=np.int64)
+            return cls, counters
         if not isinstance(test_set, torch.Tensor):
             # host arrays (the reference's call shape): pipelined PCIe transfers + decode
             return net.decode_host(np.asarray(test_set), labels, tile_bits=tile_bits)

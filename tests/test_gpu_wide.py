@@ -116,3 +116,19 @@ def test_train_and_evaluate_end_to_end(cuda_device, tmp_path):
         again = sq.train_and_evaluate(cfg)
     assert f"Model loaded from {path}" in b2.getvalue()
     assert np.array_equal(again["predictions"], out["predictions"])
+
+
+def test_fnn_api_falls_back_to_the_wide_path_for_other_hidden_widths(cuda_device):
+    """n_hidden_* are free parameters of the reference's DecoderConfig; widths the fused kernel has no
+    instantiation for are decoded by the layer-at-a-time HIP path (still on the GPU)."""
+    cfg = fv.DecoderConfig(block_length=7, n_hidden_1=200, n_hidden_2=96, n_hidden_3=48,
+                           samples_per_class_train=1, samples_per_class_test=3)
+    weights, biases = fv.initialize_weights(cfg, rng=np.random.RandomState(2))
+    np.random.seed(4)
+    _, _, te, tel, _ = fv.train_test_dataset(cfg)
+    labels = np.argmax(tel, 1).astype(np.int32)
+    preds, counters = fv.predict(te, weights, biases, labels=labels, tile_bits=7)
+    Ws, bs = fv.weights_as_lists(weights, biases)
+    out = fv.multilayer_perceptron(te, weights, biases)
+    _check(preds, out, te, Ws, bs)
+    assert np.array_equal(counters, O.error_counters(preds, labels, 7))
