@@ -28,7 +28,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
-constexpr int kBM = kDenseBM, kBN = kDenseBN, kBK = kDenseBK, kLdsStride = 36;
+constexpr int kBM = kDenseBM, kBN = kDenseBN;
 
 __device__ __forceinline__ float dense_tanh_f32(float z) {
   const float e = __builtin_amdgcn_exp2f(z * 2.8853900817779268f);
@@ -36,8 +36,12 @@ __device__ __forceinline__ float dense_tanh_f32(float z) {
   return __builtin_fmaf(-2.0f, r, 1.0f);
 }
 
-template <bool GATHER>
+// BK = 32 (row stride 36 floats) or 64 (68): both strides make every b128 access conflict free.
+template <bool GATHER, int kBK>
 __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
+  constexpr int kLdsStride = kBK + 4;
+  constexpr int kPasses = kBK / 8;          // float4 loads per thread per operand per k-tile
+  constexpr int kRowsPerPass = 1024 / kBK;  // 32 (BK 32) or 16 (BK 64)
   __shared__ __attribute__((aligned(16))) float lds_a[kBM * kLdsStride];
   __shared__ __attribute__((aligned(16))) float lds_w[kBN * kLdsStride];
 
@@ -60,15 +64,15 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
   const int col0 = col_blk * kBN;
 
   // global -> register staging: 128 rows x 32 k = 1024 float4, 4 per thread
-  const int ld_row = tid >> 3;       // 0..31 (+32 per pass)
-  const int ld_kq = (tid & 7) * 4;   // 0,4,..,28
-  f32x4 ra[4], rw[4];
+  const int ld_row = tid / (kBK / 4);        // + kRowsPerPass per pass
+  const int ld_kq = (tid % (kBK / 4)) * 4;   // 0, 4, .., BK-4
+  f32x4 ra[kPasses], rw[kPasses];
 
   auto load_tiles = [&](int kt) {
     const int k = kt * kBK + ld_kq;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      int64_t r = row0 + ld_row + 32 * ps;
+    for (int ps = 0; ps < kPasses; ++ps) {
+      int64_t r = row0 + ld_row + kRowsPerPass * ps;
       r = r < p.n_rows ? r : p.n_rows - 1;
       const float *src = p.A + r * p.a_row_stride + k;
       if (GATHER) {  // rows are only 8-byte aligned and may run past K: guarded 2-float loads
@@ -91,14 +95,14 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
       } else {
         ra[ps] = *reinterpret_cast<const f32x4 *>(src);  // activations: [rows][Kpad], 16-byte aligned
       }
-      rw[ps] = *reinterpret_cast<const f32x4 *>(p.Wt + static_cast<int64_t>(col0 + ld_row + 32 * ps) * p.Kpad + k);
+      rw[ps] = *reinterpret_cast<const f32x4 *>(p.Wt + static_cast<int64_t>(col0 + ld_row + kRowsPerPass * ps) * p.Kpad + k);
     }
   };
   auto store_tiles = [&]() {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      *reinterpret_cast<f32x4 *>(lds_a + (ld_row + 32 * ps) * kLdsStride + ld_kq) = ra[ps];
-      *reinterpret_cast<f32x4 *>(lds_w + (ld_row + 32 * ps) * kLdsStride + ld_kq) = rw[ps];
+    for (int ps = 0; ps < kPasses; ++ps) {
+      *reinterpret_cast<f32x4 *>(lds_a + (ld_row + kRowsPerPass * ps) * kLdsStride + ld_kq) = ra[ps];
+      *reinterpret_cast<f32x4 *>(lds_w + (ld_row + kRowsPerPass * ps) * kLdsStride + ld_kq) = rw[ps];
     }
   };
 
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
     __syncthreads();
     if (kt + 1 < nk) load_tiles(kt + 1);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < kBK / 8; ++g) {
       f32x4 fa[2], fb[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -195,10 +199,15 @@ __global__ __launch_bounds__(256) void head_argmax_kernel(const HeadParams p) {
 nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream) {
   const int64_t blocks = (p.nblk_rows + 7) / 8 * 8 * p.nblk_m;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return NNV_ERR_INVALID_ARGUMENT;
-  if (gather)
-    hipLaunchKernelGGL(dense_tanh_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
+  // BK = 64 measured 6 % slower than BK = 32 on the 512x512 layers (more staging registers and LDS,
+  // same MFMA count); kept as an instantiation for A/B runs only.
+  static const bool use64 = getenv("NNV_DENSE_BK64") != nullptr;
+  if (gather)  // layer 1: raw rows, K padded to 32
+    hipLaunchKernelGGL((dense_tanh_kernel<true, 32>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
+  else if (p.Kpad % 64 == 0 && use64)
+    hipLaunchKernelGGL((dense_tanh_kernel<false, 64>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
   else
-    hipLaunchKernelGGL(dense_tanh_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((dense_tanh_kernel<false, 32>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
   return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 
