@@ -182,11 +182,17 @@ int32_t nnv_awgn_generate_f32(int32_t code, int32_t tile_bits, int64_t n_rows,
  * ------------------------------------------------------------------------ */
 #define NNV_WIDE_MAX_LAYERS 8
 
+typedef enum nnv_activation {
+  NNV_ACT_TANH = 0, /* src/fnn_viterbi_seq_predict.py:408-412 */
+  NNV_ACT_RELU = 1  /* src/fnn_viterbi_bitwise.py:388-397 (output layer included) */
+} nnv_activation;
+
 typedef struct nnv_wide_desc {
   int32_t depth;                         /* 2..NNV_WIDE_MAX_LAYERS dense layers */
   int32_t dims[NNV_WIDE_MAX_LAYERS + 1]; /* dims[0] = row length, dims[depth] = n_classes */
   const float *W_host[NNV_WIDE_MAX_LAYERS]; /* [dims[l]][dims[l+1]] row-major */
   const float *b_host[NNV_WIDE_MAX_LAYERS];
+  int32_t activation;                    /* nnv_activation, applied after EVERY layer */
 } nnv_wide_desc;
 
 typedef struct nnv_wide_handle nnv_wide_handle;

@@ -44,7 +44,11 @@ class WideDesc(ctypes.Structure):
         ("dims", ctypes.c_int32 * (NNV_WIDE_MAX_LAYERS + 1)),
         ("W_host", ctypes.c_void_p * NNV_WIDE_MAX_LAYERS),
         ("b_host", ctypes.c_void_p * NNV_WIDE_MAX_LAYERS),
+        ("activation", ctypes.c_int32),
     ]
+
+
+NNV_ACTIVATION = {"tanh": 0, "relu": 1}
 
 
 class MlpDesc(ctypes.Structure):

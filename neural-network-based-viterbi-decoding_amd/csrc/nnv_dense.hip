@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
         const int64_t row = row0 + wr + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < p.n_rows) {
           float v = acc[a][b][r] + bias;
-          if (p.apply_tanh) v = dense_tanh_f32(v);
+          if (p.act == 1) v = dense_tanh_f32(v);
+          else if (p.act == 2) v = v > 0.f ? v : 0.f;
           p.C[row * p.ldc + col] = v;
         }
       }
@@ -183,7 +184,8 @@ __global__ __launch_bounds__(256) void head_argmax_kernel(const HeadParams p) {
     }
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 32);
-    const float v = dense_tanh_f32(s + p.bias[c]);
+    const float z = s + p.bias[c];
+    const float v = p.act_fn == 2 ? (z > 0.f ? z : 0.f) : dense_tanh_f32(z);
     if (p.act && live && lane == 0) p.act[row * p.n_classes + c] = v;
     if (v > best) {
       best = v;

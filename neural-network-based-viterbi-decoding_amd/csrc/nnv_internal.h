@@ -117,7 +117,7 @@ struct DenseParams {
   int64_t ldc;
   int32_t nblk_m;        // Mpad / 128
   int64_t nblk_rows;     // ceil(n_rows / 128)
-  int32_t apply_tanh;
+  int32_t act;           // 0 none, 1 tanh, 2 relu
 };
 struct HeadParams {
   const float *A;        // [n_rows][lda]
@@ -130,6 +130,7 @@ struct HeadParams {
   int32_t *cls32;
   int64_t *cls64;
   float *act;            // nullable [n_rows][n_classes]
+  int32_t act_fn;        // 1 tanh, 2 relu
 };
 nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream);
 nnv_status head_launch(const HeadParams &p, hipStream_t stream);

@@ -12,6 +12,7 @@ struct nnv_wide_handle {
   int32_t kpad[NNV_WIDE_MAX_LAYERS];  // padded input width of layer l (multiple of 32)
   int32_t mpad[NNV_WIDE_MAX_LAYERS];  // padded output width (multiple of 128; class layer: see head)
   int32_t head;                       // 1: the class layer runs in head_argmax_kernel (<= 32 classes)
+  int32_t act;                        // 1 tanh, 2 relu
   float *dev;                         // all packed weights and biases
   int64_t w_off[NNV_WIDE_MAX_LAYERS], b_off[NNV_WIDE_MAX_LAYERS];
   int32_t max_mpad;
@@ -61,6 +62,7 @@ int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out) {
   if (!net || !out) return NNV_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   if (net->depth < 2 || net->depth > NNV_WIDE_MAX_LAYERS) return NNV_ERR_UNSUPPORTED_SHAPE;
+  if (net->activation != NNV_ACT_TANH && net->activation != NNV_ACT_RELU) return NNV_ERR_INVALID_ARGUMENT;
   for (int l = 0; l <= net->depth; ++l)
     if (net->dims[l] < 1 || net->dims[l] > 16384) return NNV_ERR_INVALID_ARGUMENT;
   for (int l = 0; l < net->depth; ++l)
@@ -75,6 +77,7 @@ int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out) {
   if (!h) return NNV_ERR_OUT_OF_MEMORY;
   memset(h, 0, sizeof(*h));
   h->depth = net->depth;
+  h->act = net->activation == NNV_ACT_RELU ? 2 : 1;
   for (int l = 0; l <= net->depth; ++l) h->dims[l] = net->dims[l];
   h->head = net->dims[net->depth] <= 32 ? 1 : 0;
   int64_t total = 0;
@@ -155,6 +158,7 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev, int64_
         hp.cls32 = cls32_dev ? cls32_dev + done : nullptr;
         hp.cls64 = cls64_dev ? cls64_dev + done : nullptr;
         hp.act = act_dev ? act_dev + done * hp.n_classes : nullptr;
+        hp.act_fn = h->act;
         const nnv_status st = nnv::head_launch(hp, s);
         if (st != NNV_OK) return st;
         break;
@@ -171,7 +175,7 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev, int64_
       dp.ldc = h->mpad[l];
       dp.nblk_m = h->mpad[l] / nnv::kDenseBN;
       dp.nblk_rows = (rows + nnv::kDenseBM - 1) / nnv::kDenseBM;
-      dp.apply_tanh = 1;
+      dp.act = h->act;
       const nnv_status st = nnv::dense_launch(dp, l == 0, s);
       if (st != NNV_OK) return st;
       in = buf[cur];

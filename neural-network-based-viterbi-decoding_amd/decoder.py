@@ -324,8 +324,13 @@ class WideMLP:
     stream itself and decodes window i = stream[2i : 2i + window] without ever
     materialising the [N, window] matrix the reference builds in Python (:507-519)."""
 
-    def __init__(self, weights: Sequence, biases: Sequence, device=None, chunk_rows: int = 1 << 18):
+    def __init__(self, weights: Sequence, biases: Sequence, device=None, chunk_rows: int = 1 << 18,
+                 activation: str = "tanh"):
+        """``activation``: "tanh" (sliding-window decoder) or "relu" (bit-wise decoder,
+        src/fnn_viterbi_bitwise.py:388-397), applied after every layer, the class layer included."""
         _require_cuda()
+        if activation not in _cabi.NNV_ACTIVATION:
+            raise ValueError("activation must be 'tanh' or 'relu'")
         self._lib = _cabi.load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()
                                    if device is None else torch.device(device).index or 0)
@@ -340,6 +345,7 @@ class WideMLP:
             dims.append(W.shape[1])
         self.dims, self.n_input, self.n_classes = dims, dims[0], dims[-1]
         desc = _cabi.WideDesc()
+        desc.activation = _cabi.NNV_ACTIVATION[activation]
         desc.depth = len(Ws)
         for i, d in enumerate(dims):
             desc.dims[i] = d

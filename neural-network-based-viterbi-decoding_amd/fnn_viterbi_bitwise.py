@@ -1,0 +1,257 @@
+"""Host-side mirror of the reference's ``src/fnn_viterbi_bitwise.py``: the
+bit-wise decoder.  A block of ``block_length`` information bits is encoded with
+the (133,171) code starting from a chosen encoder state (the state bits are
+prepended to the block), and a small ReLU network ``2(6+L) -> 30 -> 2`` predicts
+ONE information bit (``bit_position``) of the block.
+
+The forward pass runs on the MI355X through the layer-at-a-time HIP path
+(``decoder.WideMLP(activation="relu")``).  Dataset generation is numpy with the
+reference's RNG consumption (golden vectors in tests/golden).
+
+Reference behaviour kept on purpose:
+  * the noisy codeword is written back into the int32 array the encoder
+    produced: soft values are truncated toward zero (SURVEY F12,
+    src/fnn_viterbi_bitwise.py:274-285,309-317);
+  * ReLU is applied on the OUTPUT layer too (:397), so the two outputs tie at
+    0.0 whenever both pre-activations are negative and argmax then says bit 0;
+  * ``weights['out']`` is [n_hidden_1, 2] drawn with stddev sqrt(2/n_hidden_4)
+    and layers h2..h4 exist as variables but are not used by the network
+    (:363-397); the L2 term still regularises h2 (:445-448);
+  * ``extract_state_bits`` raises ValueError for a state that does not fit.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import fnn_viterbi as _fv
+from .fnn_viterbi import modulate_awgn  # noqa: F401
+
+_W_KEYS = ("h1", "h2", "h3", "h4", "out")
+_B_KEYS = ("b1", "b2", "b3", "b4", "out")
+_VAR_W = {k: f"weights_{k}" for k in _W_KEYS}
+_VAR_B = {"b1": "bias_h1", "b2": "bias_h2", "b3": "bias_h3", "b4": "bias_h4", "out": "bias_out"}
+
+
+class BitwiseDecoderConfig:
+    """Same keyword arguments and derived attributes as the reference's
+    ``BitwiseDecoderConfig`` (src/fnn_viterbi_bitwise.py:29-104)."""
+
+    def __init__(self, constraint_length: int = 6, block_length: int = 512, n_hidden_1: int = 30,
+                 n_hidden_2: int = 100, n_hidden_3: int = 100, n_hidden_4: int = 100,
+                 learning_rate: float = 0.0002, training_epochs: int = 300, batch_size: int = 1000,
+                 beta_regularization: float = 0.0001, training_size: int = 300000,
+                 test_size: int = 300000, snr_db_range: Tuple[int, int] = (-2, 9),
+                 test_snr_index: int = 0, bit_position: int = 0, starting_state: int = 0):
+        self.constraint_length = constraint_length
+        self.block_length = block_length
+        self.total_length = constraint_length + block_length
+        self.n_input = 2 * self.total_length
+        self.n_hidden_1, self.n_hidden_2 = n_hidden_1, n_hidden_2
+        self.n_hidden_3, self.n_hidden_4 = n_hidden_3, n_hidden_4
+        self.n_output = 2
+        self.learning_rate = learning_rate
+        self.training_epochs = training_epochs
+        self.batch_size = batch_size
+        self.beta_regularization = beta_regularization
+        self.display_step = 1
+        self.training_size = training_size
+        self.test_size = test_size
+        snr_db_vec = np.arange(snr_db_range[0], snr_db_range[1])
+        self.snr_db_vec = snr_db_vec
+        self.snr_vec = 10 ** (snr_db_vec / 10.0)
+        self.n0_vec = 1.0 / self.snr_vec
+        self.sigma_vec = np.sqrt(self.n0_vec * 0.5)
+        self.test_snr_index = test_snr_index
+        self.bit_position = bit_position
+        self.starting_state = starting_state
+
+
+# ==============================================================================
+# encoding  (reference: src/fnn_viterbi_bitwise.py:110-215)
+# ==============================================================================
+
+
+def extract_state_bits(state_number: int, constraint_length: int = 6) -> np.ndarray:
+    """MSB-first binary digits of the state, right-aligned in ``constraint_length`` int32 slots;
+    a state needing more digits raises ValueError (src/fnn_viterbi_bitwise.py:110-137)."""
+    digits = [int(ch) for ch in format(state_number, f"0{constraint_length}b")]
+    bits = np.zeros(constraint_length, dtype=np.int32)
+    bits[len(bits) - len(digits):] = digits            # ValueError when it does not fit
+    return bits
+
+
+def encode_133171_with_state(bits: np.ndarray, state_num: int) -> np.ndarray:
+    """The (133,171) encoder run over [state bits (6), information bits] from the all-zero
+    register: 2*(6 + len(bits)) coded bits (src/fnn_viterbi_bitwise.py:140-215)."""
+    with_state = np.concatenate([extract_state_bits(state_num), np.asarray(bits)])
+    return _fv.encode_133171_batch(with_state)
+
+
+def generate_input_vectors(length: int, number: int) -> np.ndarray:
+    """``np.random.randint(2, size=(number, length))`` (src/fnn_viterbi_bitwise.py:241-252)."""
+    return np.random.randint(2, size=(number, length))
+
+
+def _encode_rows(info_seq: np.ndarray, state: int) -> np.ndarray:
+    prefix = np.broadcast_to(extract_state_bits(state), (info_seq.shape[0], 6))
+    return _fv.encode_133171_batch(np.concatenate([prefix, info_seq.astype(np.int64)], axis=1))
+
+
+def generate_training_data(config: BitwiseDecoderConfig) -> Tuple[np.ndarray, np.ndarray]:
+    """(info float32 [size, L], noisy codewords int32 [size, 2(6+L)], truncated toward zero);
+    every row gets one random SNR (src/fnn_viterbi_bitwise.py:255-287)."""
+    info_seq = generate_input_vectors(config.block_length, config.training_size).astype(np.float32)
+    encoded = _encode_rows(info_seq, config.starting_state)
+    for i in range(config.training_size):
+        snr_idx = np.random.randint(len(config.sigma_vec))
+        encoded[i, :] = modulate_awgn(encoded[i, :], config.sigma_vec[snr_idx])
+    return info_seq, encoded
+
+
+def generate_test_data(config: BitwiseDecoderConfig) -> Tuple[np.ndarray, np.ndarray]:
+    """(info int64, noisy codewords int32) at ``sigma_vec[test_snr_index]``
+    (src/fnn_viterbi_bitwise.py:290-319)."""
+    info_seq = generate_input_vectors(config.block_length, config.test_size)
+    encoded = _encode_rows(info_seq, config.starting_state)
+    test_sigma = config.sigma_vec[config.test_snr_index]
+    for i in range(config.test_size):
+        encoded[i, :] = modulate_awgn(encoded[i, :], test_sigma)
+    return info_seq, encoded
+
+
+# ==============================================================================
+# model  (reference: src/fnn_viterbi_bitwise.py:326-399)
+# ==============================================================================
+
+
+def initialize_weights(config: BitwiseDecoderConfig, rng=None) -> Tuple[Dict, Dict]:
+    """The reference's five weight variables and five zero biases with their (quirky) shapes and
+    scales (src/fnn_viterbi_bitwise.py:341-386)."""
+    c = config
+    shapes = {"h1": ((c.n_input, c.n_hidden_1), c.n_input), "h2": ((c.n_hidden_1, c.n_hidden_2), c.n_hidden_1),
+              "h3": ((c.n_hidden_2, c.n_hidden_3), c.n_hidden_2), "h4": ((c.n_hidden_3, c.n_hidden_4), c.n_hidden_3),
+              "out": ((c.n_hidden_1, c.n_output), c.n_hidden_4)}
+    weights = {k: _fv.truncated_normal(shape, math.sqrt(2.0 / fan), rng) for k, (shape, fan) in shapes.items()}
+    widths = {"b1": c.n_hidden_1, "b2": c.n_hidden_2, "b3": c.n_hidden_3, "b4": c.n_hidden_4, "out": c.n_output}
+    biases = {k: np.zeros(n, dtype=np.float32) for k, n in widths.items()}
+    return weights, biases
+
+
+def active_layers(weights: Dict, biases: Dict):
+    """The layers the network actually uses: relu(x h1 + b1) -> relu(. out + bout) (:388-397)."""
+    return [weights["h1"], weights["out"]], [biases["b1"], biases["out"]]
+
+
+def build_network(x, config: BitwiseDecoderConfig, weights: Optional[Dict] = None,
+                  biases: Optional[Dict] = None):
+    """(output, weights, biases); ``output`` = the ReLU'd class layer [N, 2] for the rows of ``x``
+    computed on the GPU (None when ``x`` is None)."""
+    if weights is None or biases is None:
+        weights, biases = initialize_weights(config)
+    output = None
+    if x is not None:
+        output = _run(x, weights, biases, want_act=True)["act"].cpu().numpy()
+    return output, weights, biases
+
+
+def _run(x, weights, biases, want_act=False, want_cls64=False):
+    import torch
+    from .decoder import WideMLP
+    net = WideMLP(*active_layers(weights, biases), activation="relu")
+    try:
+        xd = torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32)).cuda()
+        return net.decode(xd, want_act=want_act, want_cls64=want_cls64)
+    finally:
+        net.close()
+
+
+def predict(test_encoded: np.ndarray, weights: Dict, biases: Dict) -> np.ndarray:
+    """``tf.argmax(pred, 1).eval({x: test_encoded})`` (src/fnn_viterbi_bitwise.py:503-505), int64."""
+    return _run(test_encoded, weights, biases, want_cls64=True)["cls64"].cpu().numpy()
+
+
+def save_model(path: str, weights: Dict, biases: Dict) -> str:
+    path = path if path.endswith(".npz") else path + ".npz"
+    if os.path.dirname(path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+    arrays = {_VAR_W[k]: np.asarray(v, np.float32) for k, v in weights.items()}
+    arrays.update({_VAR_B[k]: np.asarray(v, np.float32) for k, v in biases.items()})
+    np.savez(path, **arrays)
+    return path
+
+
+# ==============================================================================
+# training + evaluation  (reference: src/fnn_viterbi_bitwise.py:406-515)
+# ==============================================================================
+
+
+def train_and_evaluate(config: BitwiseDecoderConfig, train_info: np.ndarray, train_encoded: np.ndarray,
+                       test_info: np.ndarray, test_encoded: np.ndarray,
+                       model_save_path: Optional[str] = None) -> Tuple[np.ndarray, float]:
+    """Adam on mean sigmoid cross-entropy taken on the ReLU outputs + beta*(l2(h1)+l2(h2)),
+    contiguous batches; then the whole test set decoded in one pass on the GPU.  Returns
+    (predictions, error_rate) and prints the reference's lines.  The trained variables are left
+    in ``train_and_evaluate.last_model``."""
+    import torch
+    dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    weights, biases = initialize_weights(config)
+    W = {k: torch.tensor(weights[k], device=dev, requires_grad=True) for k in _W_KEYS}
+    B = {k: torch.tensor(biases[k], device=dev, requires_grad=True) for k in _B_KEYS}
+    x_all = torch.as_tensor(np.asarray(train_encoded, dtype=np.float32), device=dev)
+    bit = torch.as_tensor(np.asarray(train_info)[:, config.bit_position].astype(np.int64), device=dev)
+    y_all = torch.nn.functional.one_hot(bit, 2).to(torch.float32)
+    opt = torch.optim.Adam(list(W.values()) + list(B.values()), lr=config.learning_rate)
+    bs = int(config.batch_size)
+    total_batch = int(config.training_size / bs)
+    for epoch in range(int(config.training_epochs)):
+        avg_cost = torch.zeros((), device=dev)
+        for i in range(total_batch):
+            xb, yb = x_all[i * bs:(i + 1) * bs], y_all[i * bs:(i + 1) * bs]
+            h = torch.relu(xb @ W["h1"] + B["b1"])
+            pred = torch.relu(h @ W["out"] + B["out"])
+            ce = torch.nn.functional.binary_cross_entropy_with_logits(pred, yb)
+            cost = ce + config.beta_regularization * 0.5 * ((W["h1"] ** 2).sum() + (W["h2"] ** 2).sum())
+            opt.zero_grad(set_to_none=True)
+            cost.backward()
+            opt.step()
+            avg_cost += cost.detach() / max(total_batch, 1)
+        if epoch % config.display_step == 0:
+            print(f"Epoch: {epoch + 1:04d} | cost = {float(avg_cost):.9f}")
+    print("Optimization Finished!")
+    weights = {k: v.detach().cpu().numpy().copy() for k, v in W.items()}
+    biases = {k: v.detach().cpu().numpy().copy() for k, v in B.items()}
+    if model_save_path:
+        save_model(model_save_path, weights, biases)
+        print(f"Model saved to {model_save_path}")
+    predictions = predict(test_encoded, weights, biases)
+    test_labels = np.asarray(test_info)[:, config.bit_position]
+    errors = np.sum(predictions != test_labels.astype(int))
+    error_rate = errors / len(predictions)
+    print(f"Test Error Rate: {error_rate:.6f}")
+    print(f"Test Accuracy: {1 - error_rate:.6f}")
+    train_and_evaluate.last_model = (weights, biases)
+    return predictions, error_rate
+
+
+def main() -> None:
+    print("=" * 70)
+    print("Bitwise Neural Viterbi Decoder")
+    print("=" * 70)
+    config = BitwiseDecoderConfig()
+    print("\nGenerating training data...")
+    train_info, train_encoded = generate_training_data(config)
+    print("Generating test data...")
+    test_info, test_encoded = generate_test_data(config)
+    print("\nTraining neural network...")
+    train_and_evaluate(config, train_info, train_encoded, test_info, test_encoded)
+    print("\n" + "=" * 70)
+    print("Decoding complete!")
+    print("=" * 70)
+
+
+if __name__ == "__main__":
+    main()

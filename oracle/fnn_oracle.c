@@ -43,7 +43,7 @@
  * (src/fnn_viterbi.py:432-456). */
 static void dense_tanh_row(const float *in, int n_in, const float *W,
                            const float *bias, int n_out, const int32_t *korder,
-                           float *out) {
+                           int relu, float *out) {
   for (int i = 0; i < n_out; ++i) out[i] = 0.0f;
   for (int kk = 0; kk < n_in; ++kk) {
     const int k = korder ? korder[kk] : kk;
@@ -51,7 +51,11 @@ static void dense_tanh_row(const float *in, int n_in, const float *W,
     const float *w = W + (size_t)k * n_out;
     for (int i = 0; i < n_out; ++i) out[i] = fmaf(xv, w[i], out[i]);
   }
-  for (int i = 0; i < n_out; ++i) out[i] = tanhf(out[i] + bias[i]);
+  /* tanh: src/fnn_viterbi.py:496; relu: src/fnn_viterbi_bitwise.py:388,397 */
+  if (relu)
+    for (int i = 0; i < n_out; ++i) { const float z = out[i] + bias[i]; out[i] = z > 0.0f ? z : 0.0f; }
+  else
+    for (int i = 0; i < n_out; ++i) out[i] = tanhf(out[i] + bias[i]);
 }
 
 /* Returns 0 on success, a negative value on bad arguments.
@@ -64,13 +68,15 @@ static void dense_tanh_row(const float *in, int n_in, const float *W,
  *  act_out  nullable [n_rows][dims[depth]] fp32 (the tanh'd output layer)
  *  counters nullable int64[4] = {bit_errors, frame_errors, total_bits,
  *           total_frames}; written (not accumulated); needs labels
+ *  relu     0: tanh after every layer (fnn_viterbi, seq_predict); 1: ReLU after every
+ *           layer, the class layer included (src/fnn_viterbi_bitwise.py:388-397)
  */
 int fnn_oracle_decode_f32(const float *x, int64_t n_rows, int32_t depth,
                           const int32_t *dims, const float *const *W,
                           const float *const *b, const int32_t *const *korder,
                           int32_t tile_bits, const int32_t *labels,
                           int64_t *cls_out, uint8_t *bits_out, float *act_out,
-                          int64_t *counters, int32_t n_threads) {
+                          int64_t *counters, int32_t n_threads, int32_t relu) {
   if (depth < 1 || depth > FNN_ORACLE_MAX_LAYERS || n_rows < 0) return -1;
   for (int l = 0; l <= depth; ++l)
     if (dims[l] < 1 || dims[l] > FNN_ORACLE_MAX_WIDTH) return -2;
@@ -91,7 +97,7 @@ int fnn_oracle_decode_f32(const float *x, int64_t n_rows, int32_t depth,
       float *nxt = ping;
       for (int l = 0; l < depth; ++l) {
         dense_tanh_row(cur, dims[l], W[l], b[l], dims[l + 1],
-                       korder ? korder[l] : NULL, nxt);
+                       korder ? korder[l] : NULL, relu, nxt);
         cur = nxt;
         nxt = (nxt == ping) ? pong : ping;
       }

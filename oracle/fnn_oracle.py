@@ -33,7 +33,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # --------------------------------------------------------------------------
 
 
-def forward(x, weights, biases, dtype=np.float32):
+def forward(x, weights, biases, dtype=np.float32, activation="tanh"):
     """tanh(...tanh(tanh(x W1 + b1) W2 + b2)... Wout + bout), all in ``dtype``.
 
     ``weights[l]`` is ``[n_l, n_{l+1}]`` (right-multiply, reference layout
@@ -45,7 +45,8 @@ def forward(x, weights, biases, dtype=np.float32):
     for W, b in zip(weights, biases):
         z = np.matmul(h, np.asarray(W, dtype=dtype))
         z = z + np.asarray(b, dtype=dtype)
-        h = np.tanh(z)
+        # tanh: src/fnn_viterbi.py:496; relu: src/fnn_viterbi_bitwise.py:388,397
+        h = np.tanh(z) if activation == "tanh" else np.maximum(z, np.asarray(0, dtype=dtype))
     return h
 
 
@@ -63,8 +64,8 @@ def class_to_bits(cls, b):
     return ((cls[:, None] >> shifts[None, :]) & 1).astype(np.uint8)
 
 
-def decode(x, weights, biases, b, dtype=np.float32):
-    out = forward(x, weights, biases, dtype)
+def decode(x, weights, biases, b, dtype=np.float32, activation="tanh"):
+    out = forward(x, weights, biases, dtype, activation)
     cls = argmax_first(out)
     return cls, class_to_bits(cls, b), out
 
@@ -195,7 +196,7 @@ def load_c():
             ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-            ctypes.c_void_p, ctypes.c_int32]
+            ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
         lib.fnn_oracle_max_threads.restype = ctypes.c_int
         _LIB = lib
     return _LIB
@@ -209,7 +210,7 @@ def _ptr_array(arrs):
 
 
 def decode_c(x, weights, biases, b, labels=None, korder=None, want_act=False,
-             want_bits=True, n_threads=0):
+             want_bits=True, n_threads=0, activation="tanh"):
     """Run fnn_oracle.c.  Returns dict(cls, bits, act, counters)."""
     lib = load_c()
     x = np.ascontiguousarray(x, dtype=np.float32)
@@ -235,7 +236,8 @@ def decode_c(x, weights, biases, b, labels=None, korder=None, want_act=False,
         None if lab is None else lab.ctypes.data, cls.ctypes.data,
         None if bits is None else bits.ctypes.data,
         None if act is None else act.ctypes.data,
-        None if counters is None else counters.ctypes.data, int(n_threads))
+        None if counters is None else counters.ctypes.data, int(n_threads),
+        1 if activation == "relu" else 0)
     if rc != 0:
         raise RuntimeError(f"fnn_oracle_decode_f32 failed: {rc}")
     return {"cls": cls, "bits": bits, "act": act, "counters": counters}

@@ -43,8 +43,9 @@ def _import_reference():
     import fnn_viterbi as ref_fnn  # noqa
     import fnn_viterbi_mixed_snr as ref_mix  # noqa
     import fnn_viterbi_seq_predict as ref_seq  # noqa
+    import fnn_viterbi_bitwise as ref_bit  # noqa
     sys.path.pop(0)
-    return ref_fnn, ref_mix, ref_seq
+    return ref_fnn, ref_mix, ref_seq, ref_bit
 
 
 def _capture(fn, *a, **k):
@@ -55,7 +56,7 @@ def _capture(fn, *a, **k):
 
 
 def main():
-    ref_fnn, ref_mix, ref_seq = _import_reference()
+    ref_fnn, ref_mix, ref_seq, ref_bit = _import_reference()
     arrays = {}
     meta = {}
 
@@ -248,6 +249,35 @@ def main():
     meta["seq_instance_dtypes"] = [str(inst_x[0].dtype), str(inst_y[0].dtype)]
     np.random.seed(32)
     arrays["seq_info_seq_seed32"] = ref_seq.generate_info_sequence(12)
+
+    # ---- 8. bit-wise decoder, numpy half (src/fnn_viterbi_bitwise.py) ----
+    bc = ref_bit.BitwiseDecoderConfig()
+    meta["bit_default_config"] = {"n_input": int(bc.n_input), "total_length": int(bc.total_length),
+                                  "n_output": int(bc.n_output), "n_hidden_1": int(bc.n_hidden_1),
+                                  "sigma_vec": [float(v) for v in bc.sigma_vec]}
+    meta["extract_state_bits"] = [[s_, n_, [int(v) for v in ref_bit.extract_state_bits(s_, n_)]]
+                                  for s_, n_ in ((5, 6), (0, 6), (63, 6), (1, 6), (37, 6))]
+    try:
+        ref_bit.extract_state_bits(100, 6)
+        meta["extract_state_bits_100_error"] = None
+    except Exception as e:  # noqa
+        meta["extract_state_bits_100_error"] = type(e).__name__
+    rng = np.random.RandomState(77)
+    for i, st in enumerate((0, 5, 63)):
+        bits = rng.randint(0, 2, size=10)
+        arrays[f"bit_enc_in_{i}"] = bits
+        arrays[f"bit_enc_out_{i}"] = ref_bit.encode_133171_with_state(bits, st)
+    meta["bit_enc_states"] = [0, 5, 63]
+    sb = ref_bit.BitwiseDecoderConfig(block_length=12, training_size=5, test_size=4, snr_db_range=(0, 3),
+                                      test_snr_index=1, starting_state=9)
+    np.random.seed(41)
+    bi, be = ref_bit.generate_training_data(sb)
+    ti, te2 = ref_bit.generate_test_data(sb)
+    arrays["bit_train_info"], arrays["bit_train_enc"] = bi, be
+    arrays["bit_test_info"], arrays["bit_test_enc"] = ti, te2
+    meta["bit_dtypes"] = [str(a.dtype) for a in (bi, be, ti, te2)]
+    np.random.seed(42)
+    arrays["bit_input_vectors"] = ref_bit.generate_input_vectors(7, 3)
 
     np.savez_compressed(os.path.join(HERE, "reference_numpy_half.npz"), **arrays)
     with open(os.path.join(HERE, "reference_numpy_half.json"), "w") as f:

@@ -132,3 +132,49 @@ def test_fnn_api_falls_back_to_the_wide_path_for_other_hidden_widths(cuda_device
     out = fv.multilayer_perceptron(te, weights, biases)
     _check(preds, out, te, Ws, bs)
     assert np.array_equal(counters, O.error_counters(preds, labels, 7))
+
+
+# ------------------------------------------------------------------ bit-wise decoder (ReLU)
+def test_bitwise_decoder_forward_matches_oracle(cuda_device):
+    """2(6+L) -> 30 -> 2 with ReLU on both layers (src/fnn_viterbi_bitwise.py:388-397): outputs tie
+    at 0.0 when both pre-activations are negative, and argmax then says class 0."""
+    from nnviterbi_amd import fnn_viterbi_bitwise as bw
+    cfg = bw.BitwiseDecoderConfig(block_length=512, training_size=4, test_size=3000, test_snr_index=3)
+    np.random.seed(1)
+    info, enc = bw.generate_test_data(cfg)
+    w, b = bw.initialize_weights(cfg, rng=np.random.RandomState(5))
+    b["out"] = np.array([-0.3, 0.1], dtype=np.float32)
+    Ws, bs = bw.active_layers(w, b)
+    x = enc.astype(np.float32)
+    preds = bw.predict(enc, w, b)
+    out, _, _ = bw.build_network(enc, cfg, w, b)
+    c64, _, o64 = O.decode(x, Ws, bs, 1, np.float64, activation="relu")
+    assert np.abs(out - o64).max() < 2e-5 * max(1.0, np.abs(o64).max())
+    bad = preds != c64
+    assert not bad.any() or O.top2_margin(o64)[bad].max() < 1e-4
+    ref = O.decode_c(x, Ws, bs, 1, want_bits=False, activation="relu")
+    assert (ref["cls"] != preds).sum() <= 3
+    both_zero = (o64 == 0).all(axis=1)
+    assert both_zero.any() and (preds[both_zero] == 0).all()            # ReLU'd ties -> first class
+    assert preds.dtype == np.int64 and set(np.unique(preds)) <= {0, 1}
+
+
+def test_bitwise_train_and_evaluate_end_to_end(cuda_device, tmp_path):
+    from nnviterbi_amd import fnn_viterbi_bitwise as bw
+    cfg = bw.BitwiseDecoderConfig(block_length=24, training_size=4000, test_size=1000, training_epochs=15,
+                                  batch_size=200, learning_rate=0.005, snr_db_range=(4, 8), test_snr_index=2)
+    np.random.seed(2)
+    tr_i, tr_e = bw.generate_training_data(cfg)
+    te_i, te_e = bw.generate_test_data(cfg)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        preds, err = bw.train_and_evaluate(cfg, tr_i, tr_e, te_i, te_e, model_save_path=str(tmp_path / "bw"))
+    text = buf.getvalue()
+    assert "Epoch: 0015 | cost = " in text and "Optimization Finished!" in text and "Test Error Rate: " in text
+    assert err == np.mean(preds != te_i[:, 0])      # (ReLU on the logits can die: accuracy is the reference's matter)
+    w, b = bw.train_and_evaluate.last_model
+    Ws, bs = bw.active_layers(w, b)
+    c64, _, o64 = O.decode(te_e.astype(np.float32), Ws, bs, 1, np.float64, activation="relu")
+    bad = preds != c64
+    assert not bad.any() or O.top2_margin(o64)[bad].max() < 1e-4
+    assert sorted(np.load(str(tmp_path / "bw.npz")).files)[0] == "bias_h1"

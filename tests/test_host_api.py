@@ -306,3 +306,38 @@ def test_seq_predict_weights_and_checkpoint(tmp_path):
     with pytest.raises(RuntimeError):
         with contextlib.redirect_stdout(io.StringIO()):
             sq.train_and_evaluate(cfg)                # no model_load_path: nothing to evaluate
+
+
+# ---------------------------------------------------------------- bit-wise decoder, numpy half
+def test_bitwise_numpy_half_matches_reference(golden):
+    from nnviterbi_amd import fnn_viterbi_bitwise as bw
+    g, meta = golden
+    c = bw.BitwiseDecoderConfig()
+    d = meta["bit_default_config"]
+    assert (c.n_input, c.total_length, c.n_output, c.n_hidden_1) == (d["n_input"], d["total_length"], d["n_output"], d["n_hidden_1"])
+    assert np.array_equal(c.sigma_vec, np.array(d["sigma_vec"]))
+    for s_, n_, want in meta["extract_state_bits"]:
+        got = bw.extract_state_bits(s_, n_)
+        assert got.dtype == np.int32 and got.tolist() == want
+    assert bw.extract_state_bits(5, 6).tolist() == [0, 0, 0, 1, 0, 1]     # reference tests/test_encoders.py:128-134
+    assert meta["extract_state_bits_100_error"] == "ValueError"
+    with pytest.raises(ValueError):
+        bw.extract_state_bits(100, 6)                                      # shipped code raises
+    for i, st in enumerate(meta["bit_enc_states"]):
+        out = bw.encode_133171_with_state(g[f"bit_enc_in_{i}"], st)
+        assert out.dtype == np.int32 and np.array_equal(out, g[f"bit_enc_out_{i}"])
+        assert len(out) == 2 * (6 + len(g[f"bit_enc_in_{i}"]))            # tests/test_encoders.py:136-142
+    sb = bw.BitwiseDecoderConfig(block_length=12, training_size=5, test_size=4, snr_db_range=(0, 3),
+                                 test_snr_index=1, starting_state=9)
+    np.random.seed(41)
+    bi, be = bw.generate_training_data(sb)
+    ti, te = bw.generate_test_data(sb)
+    assert [str(a.dtype) for a in (bi, be, ti, te)] == meta["bit_dtypes"]
+    assert np.array_equal(bi, g["bit_train_info"]) and np.array_equal(be, g["bit_train_enc"])
+    assert np.array_equal(ti, g["bit_test_info"]) and np.array_equal(te, g["bit_test_enc"])
+    np.random.seed(42)
+    assert np.array_equal(bw.generate_input_vectors(7, 3), g["bit_input_vectors"])
+    w, b = bw.initialize_weights(sb, rng=np.random.RandomState(0))
+    assert w["out"].shape == (sb.n_hidden_1, 2) and w["h2"].shape == (30, 100) and w["h1"].shape == (36, 30)
+    Ws, bs = bw.active_layers(w, b)
+    assert [a.shape for a in Ws] == [(36, 30), (30, 2)] and [a.shape for a in bs] == [(30,), (2,)]
