@@ -283,6 +283,12 @@ int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision, nnv_mlp_h
     delete h;
     return NNV_ERR_HIP;
   }
+  const nnv_status prep = nnv::decode_prepare(s, h->num_cus, h->lds_limit);
+  if (prep != NNV_OK) {
+    (void)hipFree(h->wpack_dev);
+    delete h;
+    return prep;
+  }
   *out = h;
   return NNV_OK;
 }

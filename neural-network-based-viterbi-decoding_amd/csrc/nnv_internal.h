@@ -102,6 +102,7 @@ nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
                          const LaunchPlan &plan, bool write_act,
                          hipStream_t stream);
 int decode_kernel_vgprs(const PackedShape &s);
+nnv_status decode_prepare(const PackedShape &s, int num_cus, int lds_limit);
 
 // nnv_dense.hip: layer-at-a-time path for wide networks
 constexpr int kDenseBM = 128, kDenseBN = 128, kDenseBK = 32;

@@ -601,21 +601,45 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
   return NNV_OK;
 }
 
+namespace {
+// dynamic LDS above the default cap must be opted into, once per kernel
+nnv_status ensure_lds_optin(const KernelEntry *k, int lds_bytes) {
+  static int lds_set[sizeof(kKernels) / sizeof(kKernels[0])] = {0};
+  const int idx = static_cast<int>(k - kKernels);
+  if (lds_set[idx] < lds_bytes) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k->fn),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+      return NNV_ERR_HIP;
+    lds_set[idx] = lds_bytes;
+  }
+  return NNV_OK;
+}
+}  // namespace
+
+// Called from prepack: every attribute a launch of this network needs is set here, so that the
+// launches themselves are pure kernel launches (capturable into a HIP graph from the first call).
+nnv_status decode_prepare(const PackedShape &s, int num_cus, int lds_limit) {
+  LaunchPlan plan;
+  const nnv_status st = decode_plan(s, 1 << 20, num_cus, lds_limit, &plan);
+  if (st != NNV_OK) return st;
+  for (const bool act : {false, true}) {
+    const KernelEntry *k = find_kernel(s, act ? 512 : plan.threads, act);
+    if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
+    const nnv_status e = ensure_lds_optin(k, plan.lds_bytes);
+    if (e != NNV_OK) return e;
+  }
+  return NNV_OK;
+}
+
 nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
                          const LaunchPlan &plan, bool write_act,
                          hipStream_t stream) {
   const int nt = write_act ? 512 : plan.threads;
   const KernelEntry *k = find_kernel(s, nt, write_act);
   if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
-  // dynamic LDS above the default cap must be opted into, once per kernel
-  static int lds_set[sizeof(kKernels) / sizeof(kKernels[0])] = {0};
-  const int idx = static_cast<int>(k - kKernels);
-  if (lds_set[idx] < plan.lds_bytes) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k->fn),
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            plan.lds_bytes) != hipSuccess)
-      return NNV_ERR_HIP;
-    lds_set[idx] = plan.lds_bytes;
+  {
+    const nnv_status e = ensure_lds_optin(k, plan.lds_bytes);
+    if (e != NNV_OK) return e;
   }
   int blocks = plan.blocks;
   if (write_act) {  // 8 waves per workgroup in the debug variant

@@ -200,6 +200,30 @@ def test_host_array_pipeline_equals_resident_decode(cuda_device, register_host):
     net.close()
 
 
+def test_decode_is_hip_graph_capturable(cuda_device):
+    """The launch path makes no allocation/synchronisation of its own (stream-ordered C ABI), so a
+    decode can be captured into a HIP graph and replayed (launch-bound small batches)."""
+    dims, b, n = [16, 128, 64, 32, 256], 8, 4096
+    Ws, bs = _net(dims, 21)
+    net = PackedMLP(Ws, bs)
+    rng = np.random.RandomState(3)
+    xs = [torch.from_numpy(rng.randn(n, 16).astype(np.float32)).cuda() for _ in range(2)]
+    x = xs[0].clone()
+    cls = torch.empty(n, dtype=torch.int32, device="cuda")
+    g = torch.cuda.CUDAGraph()                        # no warm-up launch: prepack set every kernel attribute
+    with torch.cuda.graph(g):
+        st = net._lib.nnv_mlp_decode_f32(net._handle, x.data_ptr(), n, b, None, cls.data_ptr(), None, None,
+                                         None, torch.cuda.current_stream().cuda_stream)
+        assert st == 0
+    for src in xs:
+        x.copy_(src)
+        g.replay()
+        torch.cuda.synchronize()
+        want = net.decode(src, tile_bits=b)["cls32"]
+        assert torch.equal(cls, want)
+    net.close()
+
+
 def _tanh_probe_net(z):
     """Network whose output layer is tanh(z) for chosen z: zero weights, z as the
     output bias.  32 values per probe."""

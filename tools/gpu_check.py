@@ -59,8 +59,6 @@ def bench(dims, b, n, iters=5, precision='f32'):
     cls = torch.empty(n, dtype=torch.int32, device="cuda")
     cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
     net.decode_timed(x, labels, cls, cnt, 1, tile_bits=b)
-    for nt in ("512", "1024"):
-        pass
     ms = net.decode_timed(x, labels, cls, cnt, iters, tile_bits=b) / iters
     flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
     print(f"bench [{precision}] dims={dims} n={n}: {ms:.3f} ms/launch  {n / ms / 1e3:.1f} M rows/s  "
