@@ -193,6 +193,8 @@ typedef struct nnv_wide_desc {
   const float *W_host[NNV_WIDE_MAX_LAYERS]; /* [dims[l]][dims[l+1]] row-major */
   const float *b_host[NNV_WIDE_MAX_LAYERS];
   int32_t activation;                    /* nnv_activation, applied after EVERY layer */
+  int32_t precision;                     /* nnv_precision; F16X3 needs n_classes <= 32 and
+                                            every |weight| < 65504                        */
 } nnv_wide_desc;
 
 typedef struct nnv_wide_handle nnv_wide_handle;

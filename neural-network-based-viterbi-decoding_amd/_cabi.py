@@ -45,6 +45,7 @@ class WideDesc(ctypes.Structure):
         ("W_host", ctypes.c_void_p * NNV_WIDE_MAX_LAYERS),
         ("b_host", ctypes.c_void_p * NNV_WIDE_MAX_LAYERS),
         ("activation", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
     ]
 
 

@@ -133,6 +133,39 @@ struct HeadParams {
   float *act;            // nullable [n_rows][n_classes]
   int32_t act_fn;        // 1 tanh, 2 relu
 };
+// nnv_dense_f16x3.hip: the same layer with hi/lo f16 operand planes (3 f16 MFMAs per product block)
+struct DenseF16Params {
+  const float *A_f32;     // gather mode (layer 1): fp32 rows at A_f32 + row * a_row_stride
+  int64_t a_row_stride;
+  const _Float16 *A_hi;   // otherwise: activation planes [n_rows][lda]
+  const _Float16 *A_lo;
+  int64_t lda;
+  int64_t n_rows;
+  int32_t K, Kpad;
+  const _Float16 *W_hi;   // [Mpad][Kpad] planes of W^T
+  const _Float16 *W_lo;
+  const float *bias;
+  _Float16 *C_hi;         // [n_rows][ldc]
+  _Float16 *C_lo;
+  int64_t ldc;
+  int32_t nblk_m;
+  int64_t nblk_rows;
+  int32_t act;            // 1 tanh, 2 relu
+};
+struct HeadF16Params {
+  const _Float16 *A_hi, *A_lo;
+  int64_t lda;
+  int64_t n_rows;
+  int32_t Kpad, n_classes;
+  const float *Wt;
+  const float *bias;
+  int32_t *cls32;
+  int64_t *cls64;
+  float *act;
+  int32_t act_fn;
+};
+nnv_status dense_f16x3_launch(const DenseF16Params &p, bool gather, hipStream_t stream);
+nnv_status head_f16x3_launch(const HeadF16Params &p, hipStream_t stream);
 nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream);
 nnv_status head_launch(const HeadParams &p, hipStream_t stream);
 

@@ -13,6 +13,8 @@ struct nnv_wide_handle {
   int32_t mpad[NNV_WIDE_MAX_LAYERS];  // padded output width (multiple of 128; class layer: see head)
   int32_t head;                       // 1: the class layer runs in head_argmax_kernel (<= 32 classes)
   int32_t act;                        // 1 tanh, 2 relu
+  int32_t f16x3;                      // 1: hidden layers' weights are hi/lo f16 planes (w_off = hi, wl_off = lo, in halves)
+  int64_t wl_off[NNV_WIDE_MAX_LAYERS];
   float *dev;                         // all packed weights and biases
   int64_t w_off[NNV_WIDE_MAX_LAYERS], b_off[NNV_WIDE_MAX_LAYERS];
   int32_t max_mpad;
@@ -21,6 +23,43 @@ struct nnv_wide_handle {
 namespace {
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// IEEE binary16 round-to-nearest-even (host side of the hi/lo split)
+uint16_t f2h(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x477ff000u) return static_cast<uint16_t>(sign | 0x7c00u);
+  if (x < 0x33000001u) return static_cast<uint16_t>(sign);
+  if (x < 0x38800000u) {
+    const int shift = 126 - static_cast<int>(x >> 23);
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    m >>= shift;
+    if (rem > halfway || (rem == halfway && (m & 1u))) ++m;
+    return static_cast<uint16_t>(sign | m);
+  }
+  uint32_t h = ((x >> 23) - 112u) << 10 | ((x >> 13) & 0x3ffu);
+  const uint32_t rem = x & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+  return static_cast<uint16_t>(sign | h);
+}
+float h2f(uint16_t h) {
+  const uint32_t sign = (h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+  if (e == 0) {
+    if (m == 0) x = sign;
+    else {
+      e = 113;
+      while (!(m & 0x400u)) { m <<= 1; --e; }
+      x = sign | (e << 23) | ((m & 0x3ffu) << 13);
+    }
+  } else x = sign | ((e + 112u) << 23) | (m << 13);
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
 
 // first-maximum argmax over the first n_classes entries of each row (class counts > 32)
 __global__ __launch_bounds__(256) void row_argmax_kernel(const float *A, int64_t lda, int64_t n_rows,
@@ -80,6 +119,15 @@ int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out) {
   h->act = net->activation == NNV_ACT_RELU ? 2 : 1;
   for (int l = 0; l <= net->depth; ++l) h->dims[l] = net->dims[l];
   h->head = net->dims[net->depth] <= 32 ? 1 : 0;
+  h->f16x3 = net->precision == NNV_PRECISION_F16X3 ? 1 : 0;
+  if (net->precision != NNV_PRECISION_F32 && net->precision != NNV_PRECISION_F16X3) {
+    delete h;
+    return NNV_ERR_INVALID_ARGUMENT;
+  }
+  if (h->f16x3 && !h->head) {  // the split path ends in the narrow head kernel
+    delete h;
+    return NNV_ERR_UNSUPPORTED_SHAPE;
+  }
   int64_t total = 0;
   for (int l = 0; l < net->depth; ++l) {
     const bool is_head = h->head && l == net->depth - 1;
@@ -87,7 +135,7 @@ int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out) {
     h->kpad[l] = l == 0 ? round_up(net->dims[0], nnv::kDenseBK) : h->mpad[l - 1];
     h->mpad[l] = is_head ? net->dims[l + 1] : round_up(net->dims[l + 1], nnv::kDenseBN);
     if (!is_head && h->mpad[l] > h->max_mpad) h->max_mpad = h->mpad[l];
-    h->w_off[l] = total;
+    h->w_off[l] = total;   // fp32: [mpad][kpad] floats; f16x3 hidden layer: hi plane then lo plane (same bytes)
     total += static_cast<int64_t>(h->mpad[l]) * h->kpad[l];
     h->b_off[l] = total;
     total += round_up(h->mpad[l], 4);
@@ -96,8 +144,25 @@ int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out) {
   for (int l = 0; l < net->depth; ++l) {
     const int K = net->dims[l], M = net->dims[l + 1];
     float *wt = host.data() + h->w_off[l];
-    for (int m = 0; m < M; ++m)
-      for (int k = 0; k < K; ++k) wt[static_cast<size_t>(m) * h->kpad[l] + k] = net->W_host[l][static_cast<size_t>(k) * M + m];
+    const bool planes = h->f16x3 && !(h->head && l == net->depth - 1);
+    if (planes) {
+      uint16_t *hi = reinterpret_cast<uint16_t *>(wt);
+      uint16_t *lo = hi + static_cast<size_t>(h->mpad[l]) * h->kpad[l];
+      for (int m = 0; m < M; ++m)
+        for (int k = 0; k < K; ++k) {
+          const float v = net->W_host[l][static_cast<size_t>(k) * M + m];
+          if (!(v > -65504.f && v < 65504.f)) {
+            delete h;
+            return NNV_ERR_UNSUPPORTED_SHAPE;
+          }
+          const uint16_t hh = f2h(v);
+          hi[static_cast<size_t>(m) * h->kpad[l] + k] = hh;
+          lo[static_cast<size_t>(m) * h->kpad[l] + k] = f2h(v - h2f(hh));
+        }
+    } else {
+      for (int m = 0; m < M; ++m)
+        for (int k = 0; k < K; ++k) wt[static_cast<size_t>(m) * h->kpad[l] + k] = net->W_host[l][static_cast<size_t>(k) * M + m];
+    }
     for (int m = 0; m < M; ++m) host[h->b_off[l] + m] = net->b_host[l][m];
   }
   if (hipMalloc(reinterpret_cast<void **>(&h->dev), host.size() * sizeof(float)) != hipSuccess) {
@@ -146,6 +211,55 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev, int64_
     int64_t in_stride = row_stride;
     int cur = 0;
     for (int l = 0; l < h->depth; ++l) {
+      if (h->f16x3) {
+        // activations as hi/lo planes: buffer = [chunk][max_mpad] halves hi, then the same for lo
+        _Float16 *out_hi = reinterpret_cast<_Float16 *>(buf[cur]);
+        _Float16 *out_lo = out_hi + chunk * h->max_mpad;
+        const _Float16 *in_hi = reinterpret_cast<const _Float16 *>(in);
+        const _Float16 *in_lo = in_hi + chunk * h->max_mpad;
+        if (l == last) {
+          nnv::HeadF16Params hp;
+          hp.A_hi = in_hi;
+          hp.A_lo = in_lo;
+          hp.lda = in_stride;
+          hp.n_rows = rows;
+          hp.Kpad = h->kpad[l];
+          hp.n_classes = h->dims[h->depth];
+          hp.Wt = h->dev + h->w_off[l];
+          hp.bias = h->dev + h->b_off[l];
+          hp.cls32 = cls32_dev ? cls32_dev + done : nullptr;
+          hp.cls64 = cls64_dev ? cls64_dev + done : nullptr;
+          hp.act = act_dev ? act_dev + done * hp.n_classes : nullptr;
+          hp.act_fn = h->act;
+          const nnv_status st = nnv::head_f16x3_launch(hp, s);
+          if (st != NNV_OK) return st;
+          break;
+        }
+        nnv::DenseF16Params dp;
+        dp.A_f32 = in;
+        dp.a_row_stride = in_stride;
+        dp.A_hi = in_hi;
+        dp.A_lo = in_lo;
+        dp.lda = in_stride;
+        dp.n_rows = rows;
+        dp.K = h->dims[l];
+        dp.Kpad = h->kpad[l];
+        dp.W_hi = reinterpret_cast<const _Float16 *>(h->dev + h->w_off[l]);
+        dp.W_lo = dp.W_hi + static_cast<int64_t>(h->mpad[l]) * h->kpad[l];
+        dp.bias = h->dev + h->b_off[l];
+        dp.C_hi = out_hi;
+        dp.C_lo = out_lo;
+        dp.ldc = h->mpad[l];
+        dp.nblk_m = h->mpad[l] / nnv::kDenseBN;
+        dp.nblk_rows = (rows + nnv::kDenseBM - 1) / nnv::kDenseBM;
+        dp.act = h->act;
+        const nnv_status st = nnv::dense_f16x3_launch(dp, l == 0, s);
+        if (st != NNV_OK) return st;
+        in = buf[cur];
+        in_stride = h->mpad[l];
+        cur ^= 1;
+        continue;
+      }
       if (l == last && h->head) {
         nnv::HeadParams hp;
         hp.A = in;

@@ -325,12 +325,17 @@ class WideMLP:
     materialising the [N, window] matrix the reference builds in Python (:507-519)."""
 
     def __init__(self, weights: Sequence, biases: Sequence, device=None, chunk_rows: int = 1 << 18,
-                 activation: str = "tanh"):
+                 activation: str = "tanh", precision: str = "f32"):
         """``activation``: "tanh" (sliding-window decoder) or "relu" (bit-wise decoder,
-        src/fnn_viterbi_bitwise.py:388-397), applied after every layer, the class layer included."""
+        src/fnn_viterbi_bitwise.py:388-397), applied after every layer, the class layer included.
+        ``precision``: "f32" (exact fp32 MFMA) or "f16x3" (hi/lo f16 operand planes, fp32
+        accumulate; class layers of at most 32 classes)."""
         _require_cuda()
         if activation not in _cabi.NNV_ACTIVATION:
             raise ValueError("activation must be 'tanh' or 'relu'")
+        if precision not in _cabi.NNV_PRECISION:
+            raise ValueError(f"precision must be one of {sorted(_cabi.NNV_PRECISION)}")
+        self.precision = precision
         self._lib = _cabi.load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()
                                    if device is None else torch.device(device).index or 0)
@@ -346,6 +351,7 @@ class WideMLP:
         self.dims, self.n_input, self.n_classes = dims, dims[0], dims[-1]
         desc = _cabi.WideDesc()
         desc.activation = _cabi.NNV_ACTIVATION[activation]
+        desc.precision = _cabi.NNV_PRECISION[precision]
         desc.depth = len(Ws)
         for i, d in enumerate(dims):
             desc.dims[i] = d

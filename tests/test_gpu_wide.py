@@ -38,12 +38,13 @@ def _stream(n_windows, window, seed):
     return np.trunc(rng.choice([-1.0, 1.0], n) + 0.8 * rng.randn(n)).astype(np.float32)   # int-valued, like F12
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("n", [1, 127, 128, 129, 5000])
-def test_sliding_window_decoder_matches_oracle(cuda_device, n):
+def test_sliding_window_decoder_matches_oracle(cuda_device, n, precision):
     """Reference shape 200 -> 500 -> 500 -> 500 -> 500 -> 2 (src/fnn_viterbi_seq_predict.py:343-414)."""
     dims = [200, 500, 500, 500, 500, 2]
     Ws, bs = _net(dims, 3)
-    net = WideMLP(Ws, bs, chunk_rows=1024)            # several chunks at n = 5000
+    net = WideMLP(Ws, bs, chunk_rows=1024, precision=precision)   # several chunks at n = 5000
     s = _stream(n, 200, n)
     r = net.decode_stream(torch.from_numpy(s).cuda(), n, want_act=True, want_cls64=True)
     x = np.ascontiguousarray(np.lib.stride_tricks.sliding_window_view(s, 200)[::2][:n])
@@ -80,6 +81,12 @@ def test_wide_path_argument_errors(cuda_device):
     assert net.decode_stream(s, 0)["cls32"].numel() == 0
     with pytest.raises(ValueError):
         WideMLP([np.zeros((8, 2), np.float32)], [np.zeros(2, np.float32)])   # depth 1
+    with pytest.raises(nnviterbi_amd.NNViterbiError):
+        WideMLP(*_net([16, 256, 128], 0), precision="f16x3")                  # split path needs <= 32 classes
+    Wbig, bbig = _net([200, 500, 2], 0)
+    Wbig[0][0, 0] = 1e5
+    with pytest.raises(nnviterbi_amd.NNViterbiError):
+        WideMLP(Wbig, bbig, precision="f16x3")                                # weight outside the f16 range
     net.close()
 
 
@@ -140,6 +147,7 @@ def test_bitwise_decoder_forward_matches_oracle(cuda_device):
     at 0.0 when both pre-activations are negative, and argmax then says class 0."""
     from nnviterbi_amd import fnn_viterbi_bitwise as bw
     cfg = bw.BitwiseDecoderConfig(block_length=512, training_size=4, test_size=3000, test_snr_index=3)
+    from nnviterbi_amd.decoder import WideMLP as _W
     np.random.seed(1)
     info, enc = bw.generate_test_data(cfg)
     w, b = bw.initialize_weights(cfg, rng=np.random.RandomState(5))
@@ -178,3 +186,16 @@ def test_bitwise_train_and_evaluate_end_to_end(cuda_device, tmp_path):
     bad = preds != c64
     assert not bad.any() or O.top2_margin(o64)[bad].max() < 1e-4
     assert sorted(np.load(str(tmp_path / "bw.npz")).files)[0] == "bias_h1"
+
+
+def test_relu_network_in_f16x3_precision(cuda_device):
+    dims = [1036, 30, 2]
+    Ws, bs = _net(dims, 9)
+    x = np.trunc(np.random.RandomState(2).randn(2000, 1036) * 1.5).astype(np.float32)
+    net = WideMLP(Ws, bs, activation="relu", precision="f16x3")
+    r = net.decode(torch.from_numpy(x).cuda(), want_act=True)
+    c64, _, o64 = O.decode(x, Ws, bs, 1, np.float64, activation="relu")
+    assert np.abs(r["act"].cpu().numpy() - o64).max() < 2e-5 * max(1.0, np.abs(o64).max())
+    bad = r["cls32"].cpu().numpy() != c64
+    assert not bad.any() or O.top2_margin(o64)[bad].max() < 1e-4
+    net.close()

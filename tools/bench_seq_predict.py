@@ -32,6 +32,16 @@ for _ in range(args.steps):
     r = net.decode_stream(stream, n)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / args.steps
+fast = WideMLP(Ws, bs, precision="f16x3")
+for _ in range(2):
+    rf = fast.decode_stream(stream, n)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(args.steps):
+    rf = fast.decode_stream(stream, n)
+e1.record(); torch.cuda.synchronize()
+ms_fast = e0.elapsed_time(e1) / args.steps
+fast_diff = int((rf["cls32"] != r["cls32"]).sum().item())
 dims = sq.layer_dims(cfg)
 flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
 m = 20_000
@@ -47,4 +57,6 @@ print(json.dumps({
     "cpu_baseline": {"value": m / dt, "unit": "bits/s", "cores": threads, "kind": "port",
                      "sample": f"first {m} windows, oracle/fnn_oracle.c"},
     "parity_sample": {"windows": m, "class_mismatches": mism},
+    "fast_mode": {"dtype": "f16x3", "value": n / (ms_fast * 1e-3), "unit": "bits/s", "ms_per_step": ms_fast,
+                  "classes_differing_from_f32": fast_diff},
 }))

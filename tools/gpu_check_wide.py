@@ -36,14 +36,20 @@ x2 = rng.randn(777, 14).astype(np.float32)
 r3 = w2.decode(torch.from_numpy(x2).cuda(), want_act=True)
 c64, _, o64 = O.decode(x2, W2, b2, 7, np.float64)
 print("generic: mismatch vs fp64", (r3["cls32"].cpu().numpy() != c64).sum(), "max|act-fp64|", np.abs(r3["act"].cpu().numpy() - o64).max())
+# f16x3 precision
+wf = WideMLP(Ws, bs, precision="f16x3")
+rf = wf.decode_stream(sd, n, want_act=True)
+c64, _, o64 = O.decode(np.ascontiguousarray(x), Ws, bs, 1, np.float64)
+print("f16x3 stream: mismatch vs fp64", (rf["cls32"].cpu().numpy() != c64).sum(), "max|act-fp64|", np.abs(rf["act"].cpu().numpy() - o64).max())
 # timing: 1M windows
 nbig = 1_000_000
 big = torch.from_numpy(np.trunc(rng.randn(2 * nbig + 200)).astype(np.float32)).cuda()
 w.decode_stream(big, nbig); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for rep in range(2):
+wf.decode_stream(big, nbig)
+for rep, net_ in enumerate((w, wf)):
     t0 = time.perf_counter(); e0.record()
-    for _ in range(5): w.decode_stream(big, nbig)
+    for _ in range(5): net_.decode_stream(big, nbig)
     e1.record(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
     flop = 2 * sum(dims[i] * dims[i+1] for i in range(5))
-    print(f"1M windows: wall {dt*1e3:.2f} ms, events {e0.elapsed_time(e1)/5:.2f} ms  {nbig/dt/1e6:.1f} M bits/s  {flop*nbig/dt/1e12:.1f} TFLOP/s algorithmic")
+    print(("f32  " if rep == 0 else "f16x3") + f" 1M windows: wall {dt*1e3:.2f} ms, events {e0.elapsed_time(e1)/5:.2f} ms  {nbig/dt/1e6:.1f} M bits/s  {flop*nbig/dt/1e12:.1f} TFLOP/s algorithmic")
