@@ -25,6 +25,8 @@
 //  * Received soft bits are read once, as per-lane contiguous half rows
 //    (a wave reads one contiguous 32*n_in*4-byte span), prefetched one tile
 //    ahead; decoded classes are written as one 128-byte store per tile.
+#include <mutex>
+
 #include "nnv_internal.h"
 
 namespace nnv {
@@ -605,6 +607,8 @@ namespace {
 // dynamic LDS above the default cap must be opted into, once per kernel
 nnv_status ensure_lds_optin(const KernelEntry *k, int lds_bytes) {
   static int lds_set[sizeof(kKernels) / sizeof(kKernels[0])] = {0};
+  static std::mutex mu;  // prepack / launches may come from several host threads
+  const std::lock_guard<std::mutex> lock(mu);
   const int idx = static_cast<int>(k - kKernels);
   if (lds_set[idx] < lds_bytes) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k->fn),
