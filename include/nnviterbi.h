@@ -92,7 +92,10 @@ int32_t nnv_device_count(void);
 int32_t nnv_mlp_prepack(const nnv_mlp_desc *net, nnv_mlp_handle **out);
 
 /* Same, choosing the arithmetic (nnv_precision).  nnv_mlp_prepack == F32.
- * F16X3 needs every |weight| < 65504 (f16 range) and inputs within it. */
+ * F16X3 needs every |weight| < 11350 (the packed network carries the weights scaled by up
+ * to 4 log2(e), see pack_network_f16x3; f16 range 65504) and inputs within the f16 range;
+ * the fused kernel hands 1/(1+e^{2z}) instead of tanh(z) = 1 - 2/(1+e^{2z}) between layers
+ * in this mode, with the affine map folded into the next layer's packed weights. */
 int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision,
                            nnv_mlp_handle **out);
 

@@ -90,21 +90,32 @@ nnv_status shape_from_desc(const nnv_mlp_desc *net, int32_t precision, PackedSha
 }
 
 // f16x3 fragment order (nnv_internal.h).  Returns false if a weight is outside the f16 range.
+//
+// The f16x3 kernel hands r = 1 / (1 + 2^zeta), zeta = 2 log2(e) z, from layer to layer instead of
+// tanh(z) = 1 - 2r (act16 in nnv_mlp_decode.hip), so the packed network is the reference's with
+//   hidden layers scaled by c = 2 log2(e)        (their accumulators hold zeta)
+//   layers >= 2 taking r as input                (W' = -2 W,  b' = b + sum_k W_k)
+// i.e. W_eff = s_l * f_l * W and b_eff = s_l * (b + [l >= 2] sum_k W_k) with s_l = c for hidden
+// layers, 1 for the class layer, f_l = 1 for layer 1, -2 after.  Computed in double and split
+// into hi/lo halves from the double (22 significant bits), the same algebraic function.
 bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vector<float> *out) {
   out->assign(static_cast<size_t>(s.hid_floats + s.out_floats + s.bias_floats), 0.f);
   uint16_t *w = reinterpret_cast<uint16_t *>(out->data());
   bool in_range = true;
-  auto emit = [&](float v, uint16_t *hi, uint16_t *lo) {
-    if (!(v > -65504.f && v < 65504.f)) in_range = false;
-    const uint16_t h = f32_to_f16(v);
+  constexpr double kTwoLog2e = 2.8853900817779268;
+  auto emit = [&](double v, uint16_t *hi, uint16_t *lo) {
+    if (!(v > -65504.0 && v < 65504.0)) in_range = false;
+    const uint16_t h = f32_to_f16(static_cast<float>(v));
     *hi = h;
-    *lo = f32_to_f16(v - f16_to_f32(h));
+    *lo = f32_to_f16(static_cast<float>(v - static_cast<double>(f16_to_f32(h))));
   };
+  auto layer_scale = [&](int l) { return l == net->depth - 1 ? 1.0 : kTwoLog2e; };
   // a group = 64 lanes x 8 halves = 512 uint16; hi group then lo group per k-step
   {
     const int M = net->dims[1];
     const float *W = net->W_host[0];
     const int ks1 = s.g1 / 2;
+    const double sc = layer_scale(0);
     for (int mt = 0; mt < s.mt[0]; ++mt)
       for (int ks = 0; ks < ks1; ++ks) {
         for (int lane = 0; lane < 64; ++lane)
@@ -112,7 +123,7 @@ bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vect
             const int t = 8 * ks + e;
             const int k = (lane >> 5) * s.bp + t;
             const int i = 32 * mt + (lane & 31);
-            const float v = (t < s.bp && k < s.n_in && i < M) ? W[static_cast<size_t>(k) * M + i] : 0.f;
+            const double v = (t < s.bp && k < s.n_in && i < M) ? sc * W[static_cast<size_t>(k) * M + i] : 0.0;
             emit(v, w + lane * 8 + e, w + 512 + lane * 8 + e);
           }
         w += 1024;
@@ -123,6 +134,7 @@ bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vect
     const int KT = s.mt[l - 1];
     const int MT = (l == net->depth - 1) ? s.mt_out : s.mt[l];
     const float *W = net->W_host[l];
+    const double sc = -2.0 * layer_scale(l);
     for (int mt = 0; mt < MT; ++mt)
       for (int kt = 0; kt < KT; ++kt)
         for (int st = 0; st < 2; ++st) {
@@ -131,7 +143,7 @@ bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vect
               const int r = 8 * st + e;
               const int k = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
               const int i = 32 * mt + (lane & 31);
-              const float v = (k < K && i < M) ? W[static_cast<size_t>(k) * M + i] : 0.f;
+              const double v = (k < K && i < M) ? sc * W[static_cast<size_t>(k) * M + i] : 0.0;
               emit(v, w + lane * 8 + e, w + 512 + lane * 8 + e);
             }
           w += 1024;
@@ -139,9 +151,18 @@ bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vect
   }
   float *bf = reinterpret_cast<float *>(w);
   for (int l = 0; l < net->depth; ++l) {
-    const int M = net->dims[l + 1];
+    const int K = net->dims[l], M = net->dims[l + 1];
     const int MT = (l == net->depth - 1) ? s.mt_out : s.mt[l];
-    for (int i = 0; i < 32 * MT; ++i) *bf++ = i < M ? net->b_host[l][i] : 0.f;
+    for (int i = 0; i < 32 * MT; ++i) {
+      double b = 0.0;
+      if (i < M) {
+        b = net->b_host[l][i];
+        if (l >= 1)
+          for (int k = 0; k < K; ++k) b += net->W_host[l][static_cast<size_t>(k) * M + i];
+        b *= layer_scale(l);
+      }
+      *bf++ = static_cast<float>(b);
+    }
   }
   return in_range;
 }

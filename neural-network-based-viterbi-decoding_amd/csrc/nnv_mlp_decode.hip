@@ -73,14 +73,20 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
 }
 
 // 8 fp32 values -> 8 f16 "hi" + 8 f16 "lo" (one MFMA k-step's B operand each),
-// round-to-nearest-even both times (v_cvt_pk_f16_f32).
+// round-to-nearest-even both times (v_cvt_pk_f16_f32).  The residual v - hi is one
+// v_fma_mix_f32 per value (the f16 half is widened inside the FMA; exact), written as asm:
+// left to itself the compiler widens with v_cvt_f32_f16 and packs the subtractions into
+// v_pk_add_f32, which is slow beside MFMAs on gfx950.
 __device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const f32x2 x = {v[2 * q], v[2 * q + 1]};
-    const f16x2 h = __builtin_convertvector(x, f16x2);
-    const f32x2 r = x - __builtin_convertvector(h, f32x2);
-    hi[q] = __builtin_bit_cast(unsigned, h);
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x[1]));
+    const f32x2 r = {r0, r1};
+    hi[q] = h;
     lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
   }
 }
@@ -155,9 +161,20 @@ __device__ __forceinline__ f32x16 init_acc(const float *bias_tile, int half) {
   return acc;
 }
 
-__device__ __forceinline__ void tanh16(f32x16 &acc) {
+// Hidden-layer activation as the NEXT layer consumes it.
+//  fp32 : a = tanh(z), the reference's op as it stands.
+//  f16x3: r = 1 / (1 + 2^zeta) with zeta = 2 log2(e) z, so tanh(z) = 1 - 2r.  The scale is
+//         folded into this layer's packed weights and bias, the affine map 1 - 2r into the
+//         next layer's (W' = -2W, b' = b + sum_k W_k; pack_network_f16x3 in nnv_capi.hip):
+//         3 VALU instructions per activation instead of 5 in the mode that is VALU-bound.
+//         Limits stay exact: zeta -> +inf gives r = 0 (tanh 1), -inf gives r = 1 (tanh -1).
+template <int PREC>
+__device__ __forceinline__ void act16(f32x16 &acc) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = tanh_f32(acc[r]);
+  for (int r = 0; r < 16; ++r) {
+    if constexpr (PREC == kPrecF32) acc[r] = tanh_f32(acc[r]);
+    else acc[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r]));
+  }
 }
 
 // fp32 tanh returns exactly +-1.0f beyond |z| ~ 9.011 (1 - tanh z < 2^-25), for
@@ -322,7 +339,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
           acc = mfma16(ahi, xhi[s], acc);
         }
       }
-      tanh16(acc);
+      act16<PREC>(acc);
       return acc;
     };
     ActTile<PREC> ha[NHID == 1 ? MTA : 1];
@@ -350,7 +367,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       prefetched = true;
 #pragma unroll
       for (int mt = 0; mt < MTB; ++mt) {
-        tanh16(acc2[mt]);
+        act16<PREC>(acc2[mt]);
         hb[mt].set(acc2[mt]);
       }
     }
@@ -364,7 +381,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       for (int mt = 0; mt < MTC; ++mt) {
         f32x16 acc = init_acc(lds + B3OFF + 32 * mt, half);
         acc = dense_tile<PREC, MTB>(hb, lds + W1F + W2F + mt * MTB * 4 * kFragGroupFloats + lo, acc);
-        tanh16(acc);
+        act16<PREC>(acc);
         hc[mt].set(acc);
       }
     }
