@@ -42,8 +42,9 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
   constexpr int kLdsStride = kBK + 4;
   constexpr int kPasses = kBK / 8;          // float4 loads per thread per operand per k-tile
   constexpr int kRowsPerPass = 1024 / kBK;  // 32 (BK 32) or 16 (BK 64)
-  __shared__ __attribute__((aligned(16))) float lds_a[kBM * kLdsStride];
-  __shared__ __attribute__((aligned(16))) float lds_w[kBN * kLdsStride];
+  __shared__ __attribute__((aligned(16))) float lds_all[(kBM + kBN) * kLdsStride];
+  float *const lds_a = lds_all;
+  float *const lds_w = lds_all + kBM * kLdsStride;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -140,23 +141,41 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
     }
   }
 
-  // epilogue: + bias, tanh, store.  D: column (neuron) on the lane, rows in the registers.
+  // epilogue: + bias, activation, store.  D has the column (neuron) on the lane and the rows in
+  // the registers, so storing it as it stands is 64 four-byte stores per lane whose issue takes
+  // ~18 % of the launch (measured: the same kernel without its epilogue).  Instead the tile goes
+  // through the operand tiles' LDS, 64 rows at a time (register tile a of every wave), and
+  // leaves as whole 512-byte rows, 16 bytes per lane.  Staged row stride 136 floats: the two
+  // lane halves of one ds_write_b32 (rows 4 apart) land 32 banks apart -> conflict free; so are
+  // the 16-byte reads.
+  constexpr int kOutStride = kBN + 8;
+  static_assert(64 * kOutStride <= (kBM + kBN) * kLdsStride, "output staging must fit the operand tiles");
+  float *const stage = lds_all;
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int col = col0 + wc + 32 * b + li;
-    const float bias = p.bias[col];
+  for (int a = 0; a < 2; ++a) {
+    __syncthreads();  // operand tiles (a = 0) / previous half (a = 1) fully consumed
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int b = 0; b < 2; ++b) {
+      const int lcol = wc + 32 * b + li;
+      const float bias = p.bias[col0 + lcol];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + wr + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < p.n_rows) {
-          float v = acc[a][b][r] + bias;
-          if (p.act == 1) v = dense_tanh_f32(v);
-          else if (p.act == 2) v = v > 0.f ? v : 0.f;
-          p.C[row * p.ldc + col] = v;
-        }
+        const int lrow = (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;  // 0..63
+        float v = acc[a][b][r] + bias;
+        if (p.act == 1) v = dense_tanh_f32(v);
+        else if (p.act == 2) v = v > 0.f ? v : 0.f;
+        stage[lrow * kOutStride + lcol] = v;
       }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < (64 * kBN / 4) / 256; ++it) {
+      const int chunk = tid + 256 * it;  // 32 chunks of 16 B per staged row
+      const int lrow = chunk >> 5, c4 = (chunk & 31) * 4;
+      const int64_t row = row0 + (lrow >> 5) * 64 + 32 * a + (lrow & 31);
+      if (row < p.n_rows)
+        *reinterpret_cast<f32x4 *>(p.C + row * p.ldc + col0 + c4) =
+            *reinterpret_cast<const f32x4 *>(stage + lrow * kOutStride + c4);
     }
   }
 }
