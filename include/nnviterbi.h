@@ -229,6 +229,61 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev,
                             int32_t *cls32_dev, int64_t *cls64_dev,
                             float *act_dev, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Recurrent decoder (LSTM encoder -> LSTM decoder -> linear), the inference
+ * tensors of build_seq2seq_model, src/rnn_viterbi.py:235-340:
+ *   encoder LSTMCell(H) + dynamic_rnn over encoder_inputs      :289-297
+ *   decoder LSTMCell(H), initial_state = encoder final state   :302-312
+ *   decoder_logits = linear(decoder_outputs, vocab_size = 1)   :315-318
+ * TF-1.x LSTMCell arithmetic: kernel [1 + H][4H] (row 0 multiplies the scalar
+ * input, rows 1.. the previous output m), gate columns in the order i, j, f,
+ * o, c = sigmoid(f + forget_bias) c + sigmoid(i) tanh(j), m = sigmoid(o)
+ * tanh(c).  The reference script itself cannot be run.
+ * One wave carries 32 sequences through the whole recurrence with the state
+ * in registers; every array is TIME-MAJOR [T][batch], as the reference's
+ * placeholders are declared (:263-279).
+ * ------------------------------------------------------------------------ */
+typedef struct nnv_seq2seq_desc {
+  int32_t hidden;           /* H = encoder_hidden_units = decoder_hidden_units, 1..22 */
+  float forget_bias;        /* LSTMCell default 1.0 */
+  const float *enc_kernel;  /* [1 + H][4H] row-major, host */
+  const float *enc_bias;    /* [4H] */
+  const float *dec_kernel;
+  const float *dec_bias;
+  const float *proj_w;      /* [H] (the [H, 1] weights of linear()) */
+  const float *proj_b;      /* [1] */
+} nnv_seq2seq_desc;
+
+typedef struct nnv_seq2seq_handle nnv_seq2seq_handle;
+
+/* Replaces the variables created by build_seq2seq_model (:289-318) /
+ * tf.global_variables_initializer (:405): packs both cells for the current
+ * device.  Synchronous. */
+int32_t nnv_seq2seq_prepack(const nnv_seq2seq_desc *net, nnv_seq2seq_handle **out);
+int32_t nnv_seq2seq_free(nnv_seq2seq_handle *h);
+
+/*
+ * Replaces  sess.run(model['decoder_prediction'], feed_dict=test_feed_dict)
+ * (src/rnn_viterbi.py:471-474), returning the logits the prediction is taken
+ * from (tf.argmax over the size-1 vocabulary axis, :321, is identically 0 and
+ * is left to the caller).
+ *  enc_in_dev   [t_enc][batch] fp32   encoder_inputs (received soft symbols)
+ *  dec_in_dev   [t_dec][batch] fp32   decoder_inputs (EOS, info, padding :378-386)
+ *  logits_dev   nullable [t_dec][batch] fp32 out
+ *  bits_dev     nullable [n_bits][batch] uint8 out: logit > 0 for the first
+ *               n_bits decoder steps (NOT in the reference: the decision a
+ *               network trained towards +-1 targets takes)
+ *  info_dev     nullable [n_bits][batch] uint8 0/1 information bits
+ *  counters_dev nullable uint64[4] {bit_errors, frame_errors, total_bits,
+ *               total_frames} of bits vs info, ACCUMULATED; needs info_dev
+ * Asynchronous on `stream`.
+ */
+int32_t nnv_seq2seq_forward_f32(const nnv_seq2seq_handle *h, const float *enc_in_dev,
+                                const float *dec_in_dev, int32_t t_enc, int32_t t_dec,
+                                int64_t batch, float *logits_dev, uint8_t *bits_dev,
+                                const uint8_t *info_dev, int32_t n_bits,
+                                uint64_t *counters_dev, void *stream);
+
 /*
  * Timing helper used by bench.py: launches nnv_mlp_decode_f32 `iters` times
  * back-to-back on `stream` between two HIP events recorded on that same

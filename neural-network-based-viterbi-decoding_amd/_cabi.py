@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     "nnv_mlp_forward_f32", "nnv_awgn_generate_f32",
     "nnv_mlp_decode_f32_timed", "nnv_mlp_launch_info",
     "nnv_wide_prepack", "nnv_wide_free", "nnv_wide_workspace_bytes", "nnv_wide_decode_f32",
+    "nnv_seq2seq_prepack", "nnv_seq2seq_free", "nnv_seq2seq_forward_f32",
 )
 
 
@@ -50,6 +51,19 @@ class WideDesc(ctypes.Structure):
 
 
 NNV_ACTIVATION = {"tanh": 0, "relu": 1}
+
+
+class Seq2SeqDesc(ctypes.Structure):
+    _fields_ = [
+        ("hidden", ctypes.c_int32),
+        ("forget_bias", ctypes.c_float),
+        ("enc_kernel", ctypes.c_void_p),
+        ("enc_bias", ctypes.c_void_p),
+        ("dec_kernel", ctypes.c_void_p),
+        ("dec_bias", ctypes.c_void_p),
+        ("proj_w", ctypes.c_void_p),
+        ("proj_b", ctypes.c_void_p),
+    ]
 
 
 class MlpDesc(ctypes.Structure):
@@ -131,6 +145,14 @@ def load_library() -> ctypes.CDLL:
     lib.nnv_wide_decode_f32.argtypes = [
         c.c_void_p, c.c_void_p, c.c_int64, c.c_int64, c.c_void_p, c.c_int64,
         c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.nnv_seq2seq_prepack.restype = c.c_int32
+    lib.nnv_seq2seq_prepack.argtypes = [c.POINTER(Seq2SeqDesc), c.POINTER(c.c_void_p)]
+    lib.nnv_seq2seq_free.restype = c.c_int32
+    lib.nnv_seq2seq_free.argtypes = [c.c_void_p]
+    lib.nnv_seq2seq_forward_f32.restype = c.c_int32
+    lib.nnv_seq2seq_forward_f32.argtypes = [
+        c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int64,
+        c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p, c.c_void_p]
     if lib.nnv_abi_version() != NNV_ABI_VERSION:
         raise NNViterbiError(
             f"ABI mismatch: library {lib.nnv_abi_version()} != binding {NNV_ABI_VERSION}")

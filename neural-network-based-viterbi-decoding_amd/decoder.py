@@ -410,6 +410,90 @@ class WideMLP:
         return self._run(stream, n, stride, want_act, want_cls64)
 
 
+class Seq2SeqLSTM:
+    """The recurrent decoder's forward pass on the device (C ABI ``nnv_seq2seq_*``): LSTM encoder
+    over the received symbols, LSTM decoder started from the encoder's final state, linear
+    projection to one logit per decoder step (build_seq2seq_model, src/rnn_viterbi.py:235-340;
+    TF-1.x ``LSTMCell`` arithmetic, see include/nnviterbi.h).
+
+    ``params``: ``enc_kernel`` [1+H, 4H], ``enc_bias`` [4H], ``dec_kernel``, ``dec_bias``,
+    ``proj_w`` [H] or [H, 1], ``proj_b`` [1].  All activations are time-major ``[T, B]`` float32
+    CUDA tensors, the layout of the reference's placeholders (:263-279)."""
+
+    def __init__(self, params: Dict[str, np.ndarray], forget_bias: float = 1.0, device=None):
+        _require_cuda()
+        self._lib = _cabi.load_library()
+        self.device = torch.device("cuda", torch.cuda.current_device()
+                                   if device is None else torch.device(device).index or 0)
+        a = {k: _as_host_f32(params[k]) for k in
+             ("enc_kernel", "enc_bias", "dec_kernel", "dec_bias", "proj_w", "proj_b")}
+        H = a["enc_kernel"].shape[1] // 4
+        for cell in ("enc", "dec"):
+            if a[cell + "_kernel"].shape != (1 + H, 4 * H) or a[cell + "_bias"].reshape(-1).shape != (4 * H,):
+                raise ValueError("kernels must be [1 + H, 4H] and biases [4H] with one H for both cells")
+        a["proj_w"] = np.ascontiguousarray(a["proj_w"].reshape(-1))
+        a["proj_b"] = np.ascontiguousarray(a["proj_b"].reshape(-1))
+        if a["proj_w"].shape != (H,) or a["proj_b"].shape != (1,):
+            raise ValueError("proj_w must hold H weights and proj_b one bias")
+        self.hidden = H
+        desc = _cabi.Seq2SeqDesc()
+        desc.hidden = H
+        desc.forget_bias = float(forget_bias)
+        for k, v in a.items():
+            setattr(desc, k, v.ctypes.data)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _cabi.check(self._lib.nnv_seq2seq_prepack(ctypes.byref(desc), ctypes.byref(handle)),
+                        "nnv_seq2seq_prepack")
+        self._handle = handle
+
+    def close(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            self._lib.nnv_seq2seq_free(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, encoder_inputs: torch.Tensor, decoder_inputs: torch.Tensor,
+                info_bits: Optional[torch.Tensor] = None, n_bits: int = 0,
+                want_logits: bool = True, want_bits: bool = False,
+                counters: Optional[torch.Tensor] = None):
+        """``encoder_inputs`` [T_enc, B], ``decoder_inputs`` [T_dec, B].  Optional hard decisions
+        (``logit > 0`` over the first ``n_bits`` decoder steps, an extension: the reference's
+        argmax over one logit is constantly 0) as uint8 [n_bits, B], and error counters against
+        ``info_bits`` uint8 [n_bits, B] accumulated into ``counters`` int64[4]."""
+        for name, t in (("encoder_inputs", encoder_inputs), ("decoder_inputs", decoder_inputs)):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2
+                    and t.is_contiguous()):
+                raise ValueError(f"{name} must be a contiguous float32 CUDA tensor [T, B]")
+        if encoder_inputs.shape[1] != decoder_inputs.shape[1]:
+            raise ValueError("encoder and decoder inputs disagree on the batch size")
+        t_enc, batch = encoder_inputs.shape
+        t_dec = decoder_inputs.shape[0]
+        n_bits = int(n_bits)
+        if info_bits is not None:
+            if not (info_bits.is_cuda and info_bits.dtype == torch.uint8 and info_bits.is_contiguous()
+                    and tuple(info_bits.shape) == (n_bits, batch)):
+                raise ValueError("info_bits must be a contiguous uint8 CUDA tensor [n_bits, B]")
+            if counters is None:
+                counters = torch.zeros(4, dtype=torch.int64, device=self.device)
+        elif counters is not None:
+            raise ValueError("counters need info_bits")
+        logits = torch.empty((t_dec, batch), dtype=torch.float32, device=self.device) if want_logits else None
+        bits = torch.empty((n_bits, batch), dtype=torch.uint8, device=self.device) if want_bits else None
+        with torch.cuda.device(self.device):
+            st = self._lib.nnv_seq2seq_forward_f32(
+                self._handle, _ptr(encoder_inputs), _ptr(decoder_inputs), int(t_enc), int(t_dec),
+                int(batch), _ptr(logits), _ptr(bits), _ptr(info_bits), n_bits, _ptr(counters),
+                _stream_ptr(self.device))
+        _cabi.check(st, "nnv_seq2seq_forward_f32")
+        return {"logits": logits, "bits": bits, "counters": counters}
+
+
 def generate_awgn_blocks(code: str, tile_bits: int, n_rows: int, sigma, seed: int,
                          first_row: int = 0, rows_per_block: int = 1, device=None,
                          want_labels: bool = True):

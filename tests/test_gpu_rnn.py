@@ -1,0 +1,128 @@
+"""Recurrent decoder forward on the MI355X (C ABI nnv_seq2seq_*) against oracle/rnn_oracle.py.
+
+Parity: UNPINNED (the reference script cannot run and its arithmetic is un-vendored
+TensorFlow 1.x; see oracle/rnn_oracle.py).  Stated tolerance for this floating-point path:
+every decoder logit within TOL = 5e-5 absolute of the float64 restatement, for sequences of
+up to 2 x 512 recurrent steps with Glorot-scale weights (fp32 MFMA chain, v_exp_f32 / v_rcp_f32
+gates, scales folded into the packed weights); where the recurrence itself amplifies rounding
+(saturating weights) the bar is the fp32 CPU restatement's own distance from float64.  Hard bits and counters are exact integer functions of the HIP logits."""
+import numpy as np
+import pytest
+import torch
+
+import nnviterbi_amd
+from nnviterbi_amd import rnn_viterbi as rv
+from nnviterbi_amd.decoder import Seq2SeqLSTM
+from oracle import rnn_oracle as R
+
+pytestmark = pytest.mark.gpu
+TOL = 5e-5
+
+
+def _params(H, seed, scale=1.0):
+    cfg = rv.RNNDecoderConfig(encoder_hidden_units=H)
+    p = rv.initialize_parameters(cfg, rng=np.random.RandomState(seed))
+    rng = np.random.RandomState(seed + 1)
+    for k in ("enc_bias", "dec_bias", "proj_b"):
+        p[k] = (rng.randn(*p[k].shape) * 0.1).astype(np.float32)
+    p["enc_kernel"] *= scale
+    p["dec_kernel"] *= scale
+    return p
+
+
+def _inputs(t_enc, t_dec, batch, seed):
+    rng = np.random.RandomState(seed)
+    enc = np.trunc(np.sign(rng.randn(t_enc, batch)) + 0.56 * rng.randn(t_enc, batch)).astype(np.float32)
+    dec = np.sign(rng.randn(t_dec, batch)).astype(np.float32)
+    return enc, dec
+
+
+@pytest.mark.parametrize("H,t_enc,t_dec,batch", [(20, 24, 24, 100), (20, 200, 200, 65), (7, 30, 18, 33),
+                                                (1, 8, 8, 5), (22, 16, 16, 64), (13, 40, 40, 1),
+                                                (20, 0, 12, 40), (4, 12, 1, 31)])
+def test_logits_match_the_float64_restatement(cuda_device, H, t_enc, t_dec, batch):
+    p = _params(H, H + batch)
+    enc, dec = _inputs(t_enc, t_dec, batch, 7)
+    net = Seq2SeqLSTM(p)
+    r = net.forward(torch.from_numpy(enc).cuda().reshape(t_enc, batch), torch.from_numpy(dec).cuda())
+    got = r["logits"].cpu().numpy()
+    want, _ = R.seq2seq_forward(enc, dec, p, np.float64)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < TOL
+    f32, _ = R.seq2seq_forward(enc, dec, p, np.float32)      # the fp32 CPU restatement is no closer
+    assert np.abs(got - want).max() < 4 * max(np.abs(f32 - want).max(), 2e-6)
+    net.close()
+
+
+@pytest.mark.parametrize("scale", [1.0, 3.0])
+def test_long_recurrence(cuda_device, scale):
+    """BASELINE configs[4] length: block_len 256 -> 512 encoder + 512 decoder steps.  With the
+    kernels scaled x3 the gates saturate and the recurrence amplifies rounding: the fp32 CPU
+    restatement itself is then ~3e-4 away from float64, and the bar is "no worse than that"."""
+    p = _params(20, 11, scale=scale)
+    enc, dec = _inputs(512, 512, 96, 3)
+    net = Seq2SeqLSTM(p)
+    got = net.forward(torch.from_numpy(enc).cuda(), torch.from_numpy(dec).cuda())["logits"].cpu().numpy()
+    want, _ = R.seq2seq_forward(enc, dec, p, np.float64)
+    f32, _ = R.seq2seq_forward(enc, dec, p, np.float32)
+    err = np.abs(got - want).max()
+    assert err < (TOL if scale == 1.0 else max(TOL, np.abs(f32 - want).max()))
+    net.close()
+
+
+def test_bits_and_counters_are_exact_functions_of_the_logits(cuda_device):
+    p = _params(20, 5)
+    L, batch = 10, 77
+    enc, dec = _inputs(2 * L, 2 * L, batch, 9)
+    info = (np.random.RandomState(2).rand(batch, L) > 0.5).astype(np.uint8)
+    net = Seq2SeqLSTM(p)
+    counters = torch.zeros(4, dtype=torch.int64, device="cuda")
+    for _ in range(2):   # counters accumulate
+        r = net.forward(torch.from_numpy(enc).cuda(), torch.from_numpy(dec).cuda(),
+                        info_bits=torch.from_numpy(np.ascontiguousarray(info.T)).cuda(), n_bits=L,
+                        want_bits=True, counters=counters)
+    logits = r["logits"].cpu().numpy()
+    bits = r["bits"].cpu().numpy().T
+    assert np.array_equal(bits, R.hard_bits(logits, L))
+    assert np.array_equal(counters.cpu().numpy(), 2 * R.error_counters(bits, info))
+    net.close()
+
+
+def test_reference_shaped_run_and_literal_ber(cuda_device, capsys):
+    """run_seq2seq / train_seq2seq: prediction = argmax over one logit = 0, so the BER the script
+    prints is the fraction of 1 bits in the test information (src/rnn_viterbi.py:321,479-496)."""
+    cfg = rv.RNNDecoderConfig(block_length=8, encoder_hidden_units=6, training_epochs=12, batch_size=16,
+                              training_size=64, test_size=40, learning_rate=0.01)
+    np.random.seed(0)
+    train_info, train_enc, test_info, test_enc = rv.generate_datasets(cfg)
+    model = rv.build_seq2seq_model(cfg, rng=np.random.RandomState(1))
+    predictions, ber = rv.train_seq2seq(cfg, train_info, train_enc, test_info, test_enc, model=model)
+    out = capsys.readouterr().out
+    assert "Training for 12 epochs (48 batches)..." in out and "Bit Error Rate:" in out
+    assert predictions.shape == (40, 8) and not predictions.any()
+    assert ber == float((test_info == 1).sum()) / (40 * 8)
+    assert np.mean(model["loss_history"][-4:]) < np.mean(model["loss_history"][:4])   # last epoch vs first
+    feeds = rv.prepare_batch(test_info, test_enc, cfg)
+    r = rv.run_seq2seq(model, feeds, info_bits01=(test_info == 1))
+    want, pred = R.seq2seq_forward(feeds["encoder_inputs"][:, :, 0], feeds["decoder_inputs"][:, :, 0],
+                                   model["params"], np.float64)
+    assert np.abs(r["decoder_logits"] - want).max() < TOL
+    assert np.array_equal(r["decoder_prediction"], pred)
+    assert np.array_equal(r["hard_bits"], R.hard_bits(r["decoder_logits"], 8))
+    assert np.array_equal(r["counters"], R.error_counters(r["hard_bits"], test_info == 1))
+
+
+def test_errors_and_empty_batches(cuda_device):
+    with pytest.raises(nnviterbi_amd.NNViterbiError):
+        Seq2SeqLSTM(_params(23, 0))                      # no instantiation beyond 22 hidden units
+    net = Seq2SeqLSTM(_params(8, 0))
+    e = torch.empty((6, 0), dtype=torch.float32, device="cuda")
+    assert net.forward(e, e)["logits"].shape == (6, 0)
+    x = torch.zeros((6, 4), dtype=torch.float32, device="cuda")
+    with pytest.raises(ValueError):
+        net.forward(x, torch.zeros((6, 5), dtype=torch.float32, device="cuda"))
+    with pytest.raises(ValueError):
+        net.forward(x.double(), x)
+    with pytest.raises(nnviterbi_amd.NNViterbiError):     # more hard bits than decoder steps
+        net.forward(x, x, info_bits=torch.zeros((9, 4), dtype=torch.uint8, device="cuda"), n_bits=9)
+    net.close()
