@@ -228,6 +228,7 @@ nnv_status make_params(const nnv_mlp_handle *h, const float *x_dev, int64_t n_ro
   p->mt_out = s.mt_out;
   p->n_classes = s.n_classes;
   p->out_in_lds = plan->out_in_lds;
+  p->out_lds_tiles = plan->out_lds_tiles;
   p->n_bins = 1;
   p->rows_per_block = 1;
   p->first_row = 0;
@@ -440,6 +441,7 @@ int32_t nnv_mlp_launch_info(const nnv_mlp_handle *h, int64_t n_rows, int32_t *in
   info_host[6] = h->shape.depth;
   info_host[7] = h->shape.n_classes;
   info_host[8] = h->shape.precision;
+  info_host[9] = plan.out_lds_tiles;
   return NNV_OK;
 }
 

@@ -69,7 +69,8 @@ struct DecodeParams {
   int32_t xvec;        // 1: 16-byte vector loads of x are legal
   int32_t mt_out;
   int32_t n_classes;
-  int32_t out_in_lds;  // output-layer groups are LDS resident
+  int32_t out_in_lds;  // ALL output-layer groups are LDS resident
+  int32_t out_lds_tiles;  // class-layer M-tiles resident in LDS (the rest is streamed from L2)
   int32_t tile_bits;
   const int32_t *labels;
   int32_t *cls32;
@@ -92,6 +93,7 @@ struct LaunchPlan {
   int32_t blocks;
   int32_t lds_bytes;
   int32_t out_in_lds;
+  int32_t out_lds_tiles;
 };
 
 // nnv_mlp_decode.hip

@@ -248,7 +248,8 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   const int bias_floats = (BOOFF - HIDF) + 32 * p.mt_out;
   const int lds_out = BOOFF + 32 * p.mt_out;  // output groups (if resident)
   // one 32-bit work counter behind the packed network (decode_plan reserves it)
-  unsigned *tile_ctr = reinterpret_cast<unsigned *>(lds + lds_out + (p.out_in_lds ? out_floats : 0));
+  const int out_lds_floats = p.out_lds_tiles * KT_OUT * 4 * kFragGroupFloats;  // resident part of the class layer
+  unsigned *tile_ctr = reinterpret_cast<unsigned *>(lds + lds_out + out_lds_floats);
   unsigned *bin_ctr = tile_ctr + 4;  // [kMaxBins][4] u32, used only when n_bins > 1
   if (threadIdx.x == 0) *tile_ctr = 0u;
   if (threadIdx.x < kMaxBins * 4) bin_ctr[threadIdx.x] = 0u;
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       *reinterpret_cast<f32x4 *>(lds + i) = *reinterpret_cast<const f32x4 *>(g_hid + i);
     for (int i = threadIdx.x * 4; i < bias_floats; i += NT * 4)
       *reinterpret_cast<f32x4 *>(lds + HIDF + i) = *reinterpret_cast<const f32x4 *>(g_bias + i);
-    if (p.out_in_lds)
-      for (int i = threadIdx.x * 4; i < out_floats; i += NT * 4)
+    (void)out_floats;
+    for (int i = threadIdx.x * 4; i < out_lds_floats; i += NT * 4)
         *reinterpret_cast<f32x4 *>(lds + lds_out + i) = *reinterpret_cast<const f32x4 *>(g_out + i);
   }
   __syncthreads();
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     int bidx = 0;
     for (int mt = 0; mt < p.mt_out; ++mt) {
       f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
-      if (p.out_in_lds) {
+      if (mt < p.out_lds_tiles) {
         acc = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + mt * KT_OUT * 4 * kFragGroupFloats + lo, acc);
       } else {
         acc = dense_tile<PREC, KT_OUT>(
@@ -608,8 +609,13 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
   if (!find_kernel(s, 512, false)) return NNV_ERR_UNSUPPORTED_SHAPE;
   const int64_t base_floats = s.hid_floats + s.bias_floats;
   if (base_floats * 4 + kLdsTailBytes > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
-  plan->out_in_lds = ((base_floats + s.out_floats) * 4 + kLdsTailBytes <= lds_limit) ? 1 : 0;
-  plan->lds_bytes = static_cast<int32_t>((base_floats + (plan->out_in_lds ? s.out_floats : 0)) * 4) + kLdsTailBytes;  // + work counter, bin counters
+  // as many class-layer M-tiles as fit stay in LDS; the remaining ones are streamed from L2 per tile
+  const int64_t per_tile_bytes = static_cast<int64_t>(s.kt_out) * 4 * kFragGroupFloats * 4;
+  int64_t fit = (lds_limit - kLdsTailBytes - base_floats * 4) / per_tile_bytes;
+  if (fit > s.mt_out) fit = s.mt_out;
+  plan->out_lds_tiles = static_cast<int32_t>(fit);
+  plan->out_in_lds = fit == s.mt_out ? 1 : 0;
+  plan->lds_bytes = static_cast<int32_t>(base_floats * 4 + fit * per_tile_bytes) + kLdsTailBytes;  // + work counter, bin counters
   plan->threads = pick_threads(s);
   const int64_t n_tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
   const int waves = plan->threads / 64;

@@ -306,12 +306,12 @@ class PackedMLP:
         return float(ms.value)
 
     def launch_info(self, n_rows: int) -> Dict[str, int]:
-        info = (ctypes.c_int32 * 9)()
+        info = (ctypes.c_int32 * 10)()
         with torch.cuda.device(self.device):
             _cabi.check(self._lib.nnv_mlp_launch_info(self._handle, int(n_rows), info),
                         "nnv_mlp_launch_info")
         keys = ("threads", "workgroups", "lds_bytes", "vgprs", "out_layer_in_lds",
-                "rows_per_wave_tile", "depth", "n_classes", "precision")
+                "rows_per_wave_tile", "depth", "n_classes", "precision", "class_tiles_in_lds")
         return dict(zip(keys, [int(v) for v in info]))
 
 
