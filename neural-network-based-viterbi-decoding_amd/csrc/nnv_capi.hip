@@ -20,45 +20,8 @@ bool is_gfx950(const hipDeviceProp_t &prop) { return strstr(prop.gcnArchName, "g
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// IEEE binary16 round-to-nearest-even of a float (host side of the hi/lo split).
-uint16_t f32_to_f16(float f) {
-  uint32_t x;
-  memcpy(&x, &f, 4);
-  const uint32_t sign = (x >> 16) & 0x8000u;
-  x &= 0x7fffffffu;
-  if (x >= 0x7f800000u) return static_cast<uint16_t>(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
-  if (x >= 0x477ff000u) return static_cast<uint16_t>(sign | 0x7c00u);  // rounds to inf
-  if (x < 0x33000001u) return static_cast<uint16_t>(sign);              // rounds to 0
-  if (x < 0x38800000u) {                                                // subnormal half
-    const int shift = 126 - static_cast<int>(x >> 23);                  // 14..24
-    uint32_t m = (x & 0x7fffffu) | 0x800000u;
-    const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
-    m >>= shift;
-    if (rem > halfway || (rem == halfway && (m & 1u))) ++m;
-    return static_cast<uint16_t>(sign | m);
-  }
-  uint32_t h = ((x >> 23) - 112u) << 10 | ((x >> 13) & 0x3ffu);
-  const uint32_t rem = x & 0x1fffu;
-  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
-  return static_cast<uint16_t>(sign | h);
-}
-
-float f16_to_f32(uint16_t h) {
-  const uint32_t sign = (h & 0x8000u) << 16;
-  uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
-  if (e == 0) {
-    if (m == 0) x = sign;
-    else {
-      e = 113;
-      while (!(m & 0x400u)) { m <<= 1; --e; }
-      x = sign | (e << 23) | ((m & 0x3ffu) << 13);
-    }
-  } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
-  else x = sign | ((e + 112u) << 23) | (m << 13);
-  float f;
-  memcpy(&f, &x, 4);
-  return f;
-}
+using nnv::f16_to_f32;
+using nnv::f32_to_f16;
 
 nnv_status shape_from_desc(const nnv_mlp_desc *net, int32_t precision, PackedShape *s) {
   if (net->depth < 2 || net->depth > NNV_MAX_LAYERS) return NNV_ERR_UNSUPPORTED_SHAPE;

@@ -24,42 +24,8 @@ namespace {
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// IEEE binary16 round-to-nearest-even (host side of the hi/lo split)
-uint16_t f2h(float f) {
-  uint32_t x;
-  memcpy(&x, &f, 4);
-  const uint32_t sign = (x >> 16) & 0x8000u;
-  x &= 0x7fffffffu;
-  if (x >= 0x477ff000u) return static_cast<uint16_t>(sign | 0x7c00u);
-  if (x < 0x33000001u) return static_cast<uint16_t>(sign);
-  if (x < 0x38800000u) {
-    const int shift = 126 - static_cast<int>(x >> 23);
-    uint32_t m = (x & 0x7fffffu) | 0x800000u;
-    const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
-    m >>= shift;
-    if (rem > halfway || (rem == halfway && (m & 1u))) ++m;
-    return static_cast<uint16_t>(sign | m);
-  }
-  uint32_t h = ((x >> 23) - 112u) << 10 | ((x >> 13) & 0x3ffu);
-  const uint32_t rem = x & 0x1fffu;
-  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
-  return static_cast<uint16_t>(sign | h);
-}
-float h2f(uint16_t h) {
-  const uint32_t sign = (h & 0x8000u) << 16;
-  uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
-  if (e == 0) {
-    if (m == 0) x = sign;
-    else {
-      e = 113;
-      while (!(m & 0x400u)) { m <<= 1; --e; }
-      x = sign | (e << 23) | ((m & 0x3ffu) << 13);
-    }
-  } else x = sign | ((e + 112u) << 23) | (m << 13);
-  float f;
-  memcpy(&f, &x, 4);
-  return f;
-}
+inline uint16_t f2h(float f) { return nnv::f32_to_f16(f); }
+inline float h2f(uint16_t h) { return nnv::f16_to_f32(h); }
 
 // first-maximum argmax over the first n_classes entries of each row (class counts > 32)
 __global__ __launch_bounds__(256) void row_argmax_kernel(const float *A, int64_t lda, int64_t n_rows,

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Summarises the counter CSVs tools/profile_round.sh wrote:  tools/summarize_pmc.py gpurun_out/prof_<tag> [out.json]
+Per decode kernel (f32 / f16x3 instantiation of nnv::mlp_decode_kernel): per-launch mean of every counter,
+HBM bytes per launch with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE is reported in KB and
+counts 64 B per 128-B request of a wide coalesced stream -> x2; WRITE_SIZE in KB, exact), and the
+derived per-tile figures DESIGN.md quotes.  Also rewrites profiles/pmc_traffic.json (read by bench.py)."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+root = sys.argv[1]
+out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "pmc_summary.json")
+ROWS = 80_000_000
+acc = {"f32": defaultdict(list), "f16x3": defaultdict(list)}
+for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            name = r["Kernel_Name"]
+            if "mlp_decode_kernel" not in name:
+                continue
+            prec = "f16x3" if "mlp_decode_kernel<1," in name.replace(" ", "") else "f32"
+            acc[prec][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary = {"source_dir": root, "rows_per_launch": ROWS, "tiles_per_launch": ROWS // 32,
+           "correction": "gfx950: FETCH_SIZE (KB) counts 64 B per 128-B request of a wide coalesced stream -> x2; "
+                         "WRITE_SIZE (KB) exact (MI355X_MICROARCH.md, HBM section)", "kernels": {}}
+for prec, ctrs in acc.items():
+    if not ctrs:
+        continue
+    k = {"counters": {n: {"per_launch_mean": sum(v) / len(v), "launches": len(v)} for n, v in sorted(ctrs.items())}}
+    g = lambda n: k["counters"].get(n, {}).get("per_launch_mean")
+    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+        k["hbm_read_bytes_per_launch"] = g("FETCH_SIZE") * 1024 * 2
+        k["hbm_write_bytes_per_launch"] = g("WRITE_SIZE") * 1024
+        k["hbm_bytes_per_launch"] = k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]
+    tiles = ROWS // 32
+    if g("SQ_INSTS_VALU") is not None:
+        k["valu_insts_per_tile_incl_mfma"] = g("SQ_INSTS_VALU") / tiles
+        k["mfma_insts_per_tile"] = g("SQ_INSTS_MFMA") / tiles
+    if g("GRBM_GUI_ACTIVE") is not None:
+        k["kernel_cycles_per_xcd"] = g("GRBM_GUI_ACTIVE") / 8
+        k["cycles_per_tile_per_simd"] = k["kernel_cycles_per_xcd"] / (tiles / 1024)
+        if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+            k["mfma_busy_frac_per_simd"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / k["kernel_cycles_per_xcd"]
+    if g("SQ_LDS_BANK_CONFLICT") is not None:
+        k["lds_bank_conflict_cycles"] = g("SQ_LDS_BANK_CONFLICT")
+    summary["kernels"][prec] = k
+with open(out_path, "w") as f:
+    json.dump(summary, f, indent=1)
+print("wrote", out_path)
+k = summary["kernels"]
+if "f32" in k and "hbm_bytes_per_launch" in k["f32"]:
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(here, "profiles", "pmc_traffic.json"), "w") as f:
+        json.dump({"rows_per_launch": ROWS, "hbm_bytes_per_launch": k["f32"]["hbm_bytes_per_launch"],
+                   "hbm_bytes_per_launch_f16x3": k.get("f16x3", {}).get("hbm_bytes_per_launch"),
+                   "source": out_path}, f, indent=1)
+    print("updated profiles/pmc_traffic.json")
