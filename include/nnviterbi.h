@@ -246,6 +246,8 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev,
 typedef struct nnv_seq2seq_desc {
   int32_t hidden;           /* H = encoder_hidden_units = decoder_hidden_units, 1..22 */
   float forget_bias;        /* LSTMCell default 1.0 */
+  int32_t precision;        /* nnv_precision: F32 exact fp32 MFMA chain; F16X3 hi/lo f16 operand
+                               split on the 16-bit matrix pipe (every scaled |weight| < 65504) */
   const float *enc_kernel;  /* [1 + H][4H] row-major, host */
   const float *enc_bias;    /* [4H] */
   const float *dec_kernel;

@@ -57,6 +57,7 @@ class Seq2SeqDesc(ctypes.Structure):
     _fields_ = [
         ("hidden", ctypes.c_int32),
         ("forget_bias", ctypes.c_float),
+        ("precision", ctypes.c_int32),
         ("enc_kernel", ctypes.c_void_p),
         ("enc_bias", ctypes.c_void_p),
         ("dec_kernel", ctypes.c_void_p),

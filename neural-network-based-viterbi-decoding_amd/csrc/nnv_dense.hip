@@ -19,7 +19,8 @@
 // row stride so that every ds_read_b128 / ds_write_b128 is conflict free; the
 // k index inside an 8-wide group is permuted (lane half h takes k0+4h..k0+4h+3)
 // so one b128 read feeds 4 MFMAs for both operands; next k-tile's global loads
-// are issued before the MFMAs of the current one.
+// are issued before the MFMAs of the current one, and the fragment reads of k-group
+// g + 1 are interleaved with the 16 MFMAs of group g (one ds_read per four MFMAs).
 #include "nnv_internal.h"
 
 namespace nnv {
@@ -123,21 +124,33 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
     store_tiles();
     __syncthreads();
     if (kt + 1 < nk) load_tiles(kt + 1);
-#pragma unroll
-    for (int g = 0; g < kBK / 8; ++g) {
-      f32x4 fa[2], fb[2];
+    // software pipeline: group g + 1's fragments are read while group g's 16 MFMAs issue
+    f32x4 fa[2][2], fb[2][2];
+    auto read_frags = [&](int g, int buf) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        fa[t] = *reinterpret_cast<const f32x4 *>(lds_a + (wr + 32 * t + li) * kLdsStride + 8 * g + 4 * lh);
-        fb[t] = *reinterpret_cast<const f32x4 *>(lds_w + (wc + 32 * t + li) * kLdsStride + 8 * g + 4 * lh);
+        fa[buf][t] = *reinterpret_cast<const f32x4 *>(lds_a + (wr + 32 * t + li) * kLdsStride + 8 * g + 4 * lh);
+        fb[buf][t] = *reinterpret_cast<const f32x4 *>(lds_w + (wc + 32 * t + li) * kLdsStride + 8 * g + 4 * lh);
       }
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int g = 0; g < kBK / 8; ++g) {
+      if (g + 1 < kBK / 8) read_frags(g + 1, (g + 1) & 1);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][a][e], fb[g & 1][b][e], acc[a][b], 0, 0, 0);
+      if (g + 1 < kBK / 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one ds_read
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // four MFMAs
+        }
+      }
     }
   }
 

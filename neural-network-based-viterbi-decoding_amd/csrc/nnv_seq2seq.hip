@@ -31,6 +31,11 @@
 //  * sigmoid / tanh scales (-log2 e, 2 log2 e) are folded into the packed weights.
 //  * Inputs, logits, hard bits and labels are time-major [T][B]: a step's 32 rows are one
 //    128-byte line.
+//  * PREC = kPrecF16x3 (opt-in): every operand split hi/lo into two f16 and each product block
+//    computed as three v_mfma_f32_32x32x16_f16 (fp32 accumulate), as in the feed-forward kernel.
+//    One f16 MFMA spans 16 k-slots (8 per lane half), so the [h; x; 1] vector of H <= 22 units
+//    is 2 k-steps: 3 tiles x 2 steps x 3 products = 18 MFMAs per time step on the 16-bit matrix
+//    pipe, which co-executes with the gate VALU work (the fp32 MFMAs do not).
 #include <vector>
 #include <new>
 #include <string.h>
@@ -38,9 +43,10 @@
 #include "nnv_internal.h"
 
 struct nnv_seq2seq_handle {
-  int32_t hidden;   // H
-  int32_t slots;    // S (instantiated value >= ceil(H / 2))
-  float *wpack_dev; // [2 cells][3 tiles][S + 1 k-steps][64 lanes]
+  int32_t hidden;     // H
+  int32_t slots;      // S (instantiated value >= ceil(H / 2))
+  int32_t precision;  // kPrecF32 | kPrecF16x3
+  float *wpack_dev;   // fp32: [2 cells][3 tiles][S + 1 k-steps][64 lanes]; f16x3: see pack_seq2seq_f16x3
   int device;
 };
 
@@ -65,11 +71,65 @@ struct Seq2SeqParams {
 
 constexpr float kTwoLog2e = 2.8853900817779268f;
 
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+__device__ __forceinline__ f32x16 zero16() {
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  return z;
+}
+
+__device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// (a, b) -> packed f16 hi pair and lo pair, lo = f16(v - hi) by one v_fma_mix_f32 per value
+__device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsigned &lo) {
+  const f32x2 x = {a, b};
+  const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(b));
+  const f32x2 r = {r0, r1};
+  hi = h;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
+// The A operands (weights) of one LSTM cell, register resident.
+template <int S, int PREC>
+struct CellWeights;
 template <int S>
+struct CellWeights<S, kPrecF32> {
+  float w[3][S + 1];
+  __device__ __forceinline__ void load(const float *wpack, int cell, int lane) {
+#pragma unroll
+    for (int T = 0; T < 3; ++T)
+#pragma unroll
+      for (int s = 0; s < S + 1; ++s) w[T][s] = wpack[((cell * 3 + T) * (S + 1) + s) * 64 + lane];
+  }
+};
+template <int S>
+struct CellWeights<S, kPrecF16x3> {
+  u32x4 hi[3][2], lo[3][2];
+  __device__ __forceinline__ void load(const float *wpack, int cell, int lane) {
+    const u32x4 *q = reinterpret_cast<const u32x4 *>(wpack);
+#pragma unroll
+    for (int T = 0; T < 3; ++T)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        hi[T][s] = q[(((cell * 3 + T) * 2 + s) * 2 + 0) * 64 + lane];
+        lo[T][s] = q[(((cell * 3 + T) * 2 + s) * 2 + 1) * 64 + lane];
+      }
+  }
+};
+
+template <int S, int PREC>
 __global__ __launch_bounds__(256) void seq2seq_kernel(const Seq2SeqParams p) {
-  constexpr int KS = S + 1;
   constexpr int MP = 4 * S;  // projection position (half 0)
   static_assert(MP < 48, "gates + projection must fit 3 tiles");
+  static_assert(S + 1 <= 16, "[h; x] must fit the 16 k-slots a lane half has in two f16 MFMAs");
   const int lane = threadIdx.x & 63;
   const int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (tile >= p.n_tiles) return;  // whole waves only; the kernel has no barrier
@@ -78,31 +138,62 @@ __global__ __launch_bounds__(256) void seq2seq_kernel(const Seq2SeqParams p) {
   const bool live = row < p.batch;
   const int64_t row_c = live ? row : p.batch - 1;
 
-  float w[3][KS];
-  auto load_cell = [&](int cell) {
-#pragma unroll
-    for (int T = 0; T < 3; ++T)
-#pragma unroll
-      for (int s = 0; s < KS; ++s) w[T][s] = p.wpack[((cell * 3 + T) * KS + s) * 64 + lane];
-  };
+  CellWeights<S, PREC> W;
   float c[S], h[S];
 #pragma unroll
   for (int k = 0; k < S; ++k) c[k] = h[k] = 0.f;
 
+  // gate pre-activations of one step: acc[T] = W_T^T [h; xin] (xin: x_t in half 0, 1 in half 1);
+  // n_tiles_needed < 3 computes only the projection's tile (the last logit)
+  auto gates = [&](float xin, f32x16 (&acc)[3], bool proj_only) {
+    if constexpr (PREC == kPrecF32) {
+#pragma unroll
+      for (int T = 0; T < 3; ++T) {
+        if (proj_only && T != MP / 16) continue;
+        acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w[T][0], h[0], zero16(), 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < S; ++s) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w[T][s], h[s], acc[T], 0, 0, 0);
+        acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w[T][S], xin, acc[T], 0, 0, 0);
+      }
+    } else {
+      // this lane half's 16 k-slots: h[0..S-1], xin, zeros; two k-steps of 8, split hi/lo
+      u32x4 bhi[2], blo[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = 8 * s + 2 * q;
+          if (n > S) {
+            bhi[s][q] = 0u;
+            blo[s][q] = 0u;
+          } else {
+            const float v0 = n < S ? h[n < S ? n : 0] : xin;
+            const float v1 = n + 1 < S ? h[n + 1 < S ? n + 1 : 0] : (n + 1 == S ? xin : 0.f);
+            unsigned ph, pl;
+            split_pair(v0, v1, ph, pl);
+            bhi[s][q] = ph;
+            blo[s][q] = pl;
+          }
+        }
+#pragma unroll
+      for (int T = 0; T < 3; ++T) {
+        if (proj_only && T != MP / 16) continue;
+        acc[T] = zero16();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (8 * s > S) continue;               // a k-step holding only zero slots
+          acc[T] = mfma_h(W.lo[T][s], bhi[s], acc[T]);  // small terms first
+          acc[T] = mfma_h(W.hi[T][s], blo[s], acc[T]);
+          acc[T] = mfma_h(W.hi[T][s], bhi[s], acc[T]);
+        }
+      }
+    }
+  };
+
   // one LSTM step; returns the projection slot (w.h_prev + b, meaningful in half 0 of the decoder)
   auto step = [&](float xin) -> float {
     f32x16 acc[3];
-#pragma unroll
-    for (int T = 0; T < 3; ++T) {
-      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[T][0], h[0], zero, 0, 0, 0);
-    }
-#pragma unroll
-    for (int s = 1; s < S; ++s)
-#pragma unroll
-      for (int T = 0; T < 3; ++T) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[T][s], h[s], acc[T], 0, 0, 0);
-#pragma unroll
-    for (int T = 0; T < 3; ++T) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[T][S], xin, acc[T], 0, 0, 0);
+    gates(xin, acc, false);
     const float proj = acc[MP / 16][MP % 16];
 #pragma unroll
     for (int k = 0; k < S; ++k) {
@@ -125,7 +216,7 @@ __global__ __launch_bounds__(256) void seq2seq_kernel(const Seq2SeqParams p) {
   };
 
   // ------------------------------ encoder ------------------------------------------------
-  load_cell(0);
+  W.load(p.wpack, 0, lane);
   {
     float xin = (half == 0 && p.t_enc > 0) ? p.enc_in[row_c] : 1.0f;
     for (int t = 0; t < p.t_enc; ++t) {
@@ -136,7 +227,7 @@ __global__ __launch_bounds__(256) void seq2seq_kernel(const Seq2SeqParams p) {
     }
   }
   // ------------------------------ decoder ------------------------------------------------
-  load_cell(1);
+  W.load(p.wpack, 1, lane);
   unsigned bit_err = 0;
   auto emit = [&](int t, float logit) {  // logit of decoder step t, valid in half 0
     if (half != 0 || !live) return;
@@ -157,14 +248,10 @@ __global__ __launch_bounds__(256) void seq2seq_kernel(const Seq2SeqParams p) {
       if (t > 0) emit(t - 1, proj);
       xin = xnext;
     }
-    if (p.t_dec > 0) {                // last logit: the projection chain alone
-      constexpr int TP = MP / 16;
-      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[TP][0], h[0], zero, 0, 0, 0);
-#pragma unroll
-      for (int s = 1; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[TP][s], h[s], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[TP][S], half == 0 ? 0.f : 1.0f, acc, 0, 0, 0);
-      emit(p.t_dec - 1, acc[MP % 16]);
+    if (p.t_dec > 0) {                // last logit: the projection's tile alone
+      f32x16 acc[3];
+      gates(1.0f, acc, true);         // the x slot of the projection row is 0, its bias slot sees 1
+      emit(p.t_dec - 1, acc[MP / 16][MP % 16]);
     }
   }
   if (p.counters && p.info) {
@@ -187,59 +274,82 @@ __global__ __launch_bounds__(256) void seq2seq_kernel(const Seq2SeqParams p) {
 }
 
 using Seq2SeqFn = void (*)(const Seq2SeqParams);
-struct SeqEntry { int slots; Seq2SeqFn fn; };
-const SeqEntry kSeqKernels[] = {
-    {2, seq2seq_kernel<2>}, {4, seq2seq_kernel<4>}, {6, seq2seq_kernel<6>},
-    {8, seq2seq_kernel<8>}, {10, seq2seq_kernel<10>}, {11, seq2seq_kernel<11>},
-};
+struct SeqEntry { int slots, prec; Seq2SeqFn fn; };
+#define NNV_SEQ(S) {S, kPrecF32, seq2seq_kernel<S, kPrecF32>}, {S, kPrecF16x3, seq2seq_kernel<S, kPrecF16x3>}
+const SeqEntry kSeqKernels[] = {NNV_SEQ(2), NNV_SEQ(4), NNV_SEQ(6), NNV_SEQ(8), NNV_SEQ(10), NNV_SEQ(11)};
 
-const SeqEntry *find_seq_kernel(int hidden) {
+const SeqEntry *find_seq_kernel(int hidden, int prec) {
   const int need = (hidden + 1) / 2;
   for (const SeqEntry &e : kSeqKernels)
-    if (e.slots >= need) return &e;
+    if (e.slots >= need && e.prec == prec) return &e;
   return nullptr;
 }
 
-// [cell][tile][k-step][lane]; see the header comment for the placement rule.
-void pack_seq2seq(const nnv_seq2seq_desc *d, int S, std::vector<float> *out) {
-  const int H = d->hidden, KS = S + 1;
-  out->assign(static_cast<size_t>(2) * 3 * KS * 64, 0.f);
+// The packed value of (cell, tile T, output position `pos`, input k-slot n of lane half kh):
+// n < S: hidden unit kh*S + n; n == S: x_t (kh = 0) or the bias (kh = 1); see the header comment.
+double packed_weight(const nnv_seq2seq_desc *d, int S, int cell, int T, int pos, int kh, int n) {
+  const int H = d->hidden;
   const double kLog2e = 1.4426950408889634;
-  for (int cell = 0; cell < 2; ++cell) {
-    const float *kernel = cell == 0 ? d->enc_kernel : d->dec_kernel;  // [1 + H][4H]
-    const float *bias = cell == 0 ? d->enc_bias : d->dec_bias;        // [4H]
+  const float *kernel = cell == 0 ? d->enc_kernel : d->dec_kernel;  // [1 + H][4H]
+  const float *bias = cell == 0 ? d->enc_bias : d->dec_bias;        // [4H]
+  const int hh = (pos >> 2) & 1;                    // lane half that sees this output neuron
+  const int reg = 4 * (pos >> 3) + (pos & 3);
+  const int m = 16 * T + reg;                       // the half's position 0..47
+  if (n > S) return 0.0;
+  if (m < 4 * S) {
+    const int g = m / S, k = m % S, u = hh * S + k;
+    if (u >= H) return 0.0;
+    const double scale = g == 1 ? 2.0 * kLog2e : -kLog2e;
+    if (n < S) {
+      const int uin = kh * S + n;
+      return uin < H ? scale * kernel[static_cast<size_t>(1 + uin) * 4 * H + g * H + u] : 0.0;
+    }
+    if (kh == 0) return scale * kernel[g * H + u];
+    return scale * (static_cast<double>(bias[g * H + u]) + (g == 2 ? d->forget_bias : 0.0));
+  }
+  if (m == 4 * S && hh == 0 && cell == 1) {
+    if (n < S) {
+      const int uin = kh * S + n;
+      return uin < H ? d->proj_w[uin] : 0.0;
+    }
+    return kh == 1 ? d->proj_b[0] : 0.0;
+  }
+  return 0.0;
+}
+
+// fp32: [cell][tile][k-step s = slot n][lane]
+void pack_seq2seq(const nnv_seq2seq_desc *d, int S, std::vector<float> *out) {
+  const int KS = S + 1;
+  out->assign(static_cast<size_t>(2) * 3 * KS * 64, 0.f);
+  for (int cell = 0; cell < 2; ++cell)
     for (int T = 0; T < 3; ++T)
       for (int s = 0; s < KS; ++s)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int pos = lane & 31, kh = lane >> 5;
-          const int hh = (pos >> 2) & 1;                    // lane half that sees this output neuron
-          const int reg = 4 * (pos >> 3) + (pos & 3);
-          const int m = 16 * T + reg;                       // the half's position 0..47
-          double v = 0.0;
-          if (m < 4 * S) {
-            const int g = m / S, k = m % S, u = hh * S + k;
-            if (u < H) {
-              const double scale = g == 1 ? 2.0 * kLog2e : -kLog2e;
-              if (s < S) {
-                const int uin = kh * S + s;
-                if (uin < H) v = scale * kernel[static_cast<size_t>(1 + uin) * 4 * H + g * H + u];
-              } else if (kh == 0) {
-                v = scale * kernel[g * H + u];
-              } else {
-                v = scale * (static_cast<double>(bias[g * H + u]) + (g == 2 ? d->forget_bias : 0.0));
-              }
-            }
-          } else if (m == 4 * S && hh == 0 && cell == 1) {
-            if (s < S) {
-              const int uin = kh * S + s;
-              if (uin < H) v = d->proj_w[uin];
-            } else if (kh == 1) {
-              v = d->proj_b[0];
-            }
+        for (int lane = 0; lane < 64; ++lane)
+          (*out)[((static_cast<size_t>(cell) * 3 + T) * KS + s) * 64 + lane] =
+              static_cast<float>(packed_weight(d, S, cell, T, lane & 31, lane >> 5, s));
+}
+
+// f16x3: [cell][tile][k-step s < 2][hi | lo][lane][8 halves], slot n = 8 s + e.  false: a weight
+// is outside the f16 range.
+bool pack_seq2seq_f16x3(const nnv_seq2seq_desc *d, int S, std::vector<float> *out) {
+  out->assign(static_cast<size_t>(2) * 3 * 2 * 2 * 64 * 4, 0.f);
+  uint16_t *w = reinterpret_cast<uint16_t *>(out->data());
+  bool in_range = true;
+  for (int cell = 0; cell < 2; ++cell)
+    for (int T = 0; T < 3; ++T)
+      for (int s = 0; s < 2; ++s) {
+        uint16_t *hi = w + ((((static_cast<size_t>(cell) * 3 + T) * 2 + s) * 2 + 0) * 64) * 8;
+        uint16_t *lo = hi + 64 * 8;
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const double v = packed_weight(d, S, cell, T, lane & 31, lane >> 5, 8 * s + e);
+            if (!(v > -65504.0 && v < 65504.0)) in_range = false;
+            const uint16_t h = f32_to_f16(static_cast<float>(v));
+            hi[lane * 8 + e] = h;
+            lo[lane * 8 + e] = f32_to_f16(static_cast<float>(v - static_cast<double>(f16_to_f32(h))));
           }
-          (*out)[((static_cast<size_t>(cell) * 3 + T) * KS + s) * 64 + lane] = static_cast<float>(v);
-        }
-  }
+      }
+  return in_range;
 }
 
 }  // namespace
@@ -253,7 +363,8 @@ int32_t nnv_seq2seq_prepack(const nnv_seq2seq_desc *d, nnv_seq2seq_handle **out)
   if (d->hidden < 1) return NNV_ERR_INVALID_ARGUMENT;
   if (!d->enc_kernel || !d->enc_bias || !d->dec_kernel || !d->dec_bias || !d->proj_w || !d->proj_b)
     return NNV_ERR_INVALID_ARGUMENT;
-  const nnv::SeqEntry *k = nnv::find_seq_kernel(d->hidden);
+  if (d->precision != NNV_PRECISION_F32 && d->precision != NNV_PRECISION_F16X3) return NNV_ERR_INVALID_ARGUMENT;
+  const nnv::SeqEntry *k = nnv::find_seq_kernel(d->hidden, d->precision);
   if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;  // hidden > 22
   int dev = 0;
   hipDeviceProp_t prop;
@@ -261,11 +372,16 @@ int32_t nnv_seq2seq_prepack(const nnv_seq2seq_desc *d, nnv_seq2seq_handle **out)
     return NNV_ERR_NO_DEVICE;
   if (!strstr(prop.gcnArchName, "gfx950")) return NNV_ERR_NO_DEVICE;
   std::vector<float> packed;
-  nnv::pack_seq2seq(d, k->slots, &packed);
+  if (d->precision == NNV_PRECISION_F16X3) {
+    if (!nnv::pack_seq2seq_f16x3(d, k->slots, &packed)) return NNV_ERR_UNSUPPORTED_SHAPE;  // weight outside f16
+  } else {
+    nnv::pack_seq2seq(d, k->slots, &packed);
+  }
   nnv_seq2seq_handle *h = new (std::nothrow) nnv_seq2seq_handle;
   if (!h) return NNV_ERR_OUT_OF_MEMORY;
   h->hidden = d->hidden;
   h->slots = k->slots;
+  h->precision = d->precision;
   h->device = dev;
   h->wpack_dev = nullptr;
   if (hipMalloc(reinterpret_cast<void **>(&h->wpack_dev), packed.size() * sizeof(float)) != hipSuccess) {
@@ -297,7 +413,7 @@ int32_t nnv_seq2seq_forward_f32(const nnv_seq2seq_handle *h, const float *enc_in
   if ((t_enc > 0 && !enc_in_dev) || (t_dec > 0 && !dec_in_dev)) return NNV_ERR_INVALID_ARGUMENT;
   if (counters_dev && !info_dev) return NNV_ERR_INVALID_ARGUMENT;
   if ((bits_dev || info_dev) && n_bits > t_dec) return NNV_ERR_INVALID_ARGUMENT;
-  const nnv::SeqEntry *k = nnv::find_seq_kernel(h->hidden);
+  const nnv::SeqEntry *k = nnv::find_seq_kernel(h->hidden, h->precision);
   if (!k || k->slots != h->slots) return NNV_ERR_UNSUPPORTED_SHAPE;
   nnv::Seq2SeqParams p;
   p.enc_in = enc_in_dev;

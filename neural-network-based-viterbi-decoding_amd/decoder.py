@@ -420,8 +420,12 @@ class Seq2SeqLSTM:
     ``proj_w`` [H] or [H, 1], ``proj_b`` [1].  All activations are time-major ``[T, B]`` float32
     CUDA tensors, the layout of the reference's placeholders (:263-279)."""
 
-    def __init__(self, params: Dict[str, np.ndarray], forget_bias: float = 1.0, device=None):
+    def __init__(self, params: Dict[str, np.ndarray], forget_bias: float = 1.0, device=None,
+                 precision: str = "f32"):
         _require_cuda()
+        if precision not in _cabi.NNV_PRECISION:
+            raise ValueError(f"precision must be one of {sorted(_cabi.NNV_PRECISION)}")
+        self.precision = precision
         self._lib = _cabi.load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()
                                    if device is None else torch.device(device).index or 0)
@@ -439,6 +443,7 @@ class Seq2SeqLSTM:
         desc = _cabi.Seq2SeqDesc()
         desc.hidden = H
         desc.forget_bias = float(forget_bias)
+        desc.precision = _cabi.NNV_PRECISION[precision]
         for k, v in a.items():
             setattr(desc, k, v.ctypes.data)
         handle = ctypes.c_void_p()

@@ -17,6 +17,7 @@ from oracle import rnn_oracle as R
 
 pytestmark = pytest.mark.gpu
 TOL = 5e-5
+PRECISIONS = ["f32", "f16x3"]   # exact fp32 MFMA chain | hi/lo f16 split operands, fp32 accumulate
 
 
 def _params(H, seed, scale=1.0):
@@ -37,13 +38,14 @@ def _inputs(t_enc, t_dec, batch, seed):
     return enc, dec
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("H,t_enc,t_dec,batch", [(20, 24, 24, 100), (20, 200, 200, 65), (7, 30, 18, 33),
                                                 (1, 8, 8, 5), (22, 16, 16, 64), (13, 40, 40, 1),
                                                 (20, 0, 12, 40), (4, 12, 1, 31)])
-def test_logits_match_the_float64_restatement(cuda_device, H, t_enc, t_dec, batch):
+def test_logits_match_the_float64_restatement(cuda_device, precision, H, t_enc, t_dec, batch):
     p = _params(H, H + batch)
     enc, dec = _inputs(t_enc, t_dec, batch, 7)
-    net = Seq2SeqLSTM(p)
+    net = Seq2SeqLSTM(p, precision=precision)
     r = net.forward(torch.from_numpy(enc).cuda().reshape(t_enc, batch), torch.from_numpy(dec).cuda())
     got = r["logits"].cpu().numpy()
     want, _ = R.seq2seq_forward(enc, dec, p, np.float64)
@@ -54,14 +56,15 @@ def test_logits_match_the_float64_restatement(cuda_device, H, t_enc, t_dec, batc
     net.close()
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("scale", [1.0, 3.0])
-def test_long_recurrence(cuda_device, scale):
+def test_long_recurrence(cuda_device, scale, precision):
     """BASELINE configs[4] length: block_len 256 -> 512 encoder + 512 decoder steps.  With the
     kernels scaled x3 the gates saturate and the recurrence amplifies rounding: the fp32 CPU
     restatement itself is then ~3e-4 away from float64, and the bar is "no worse than that"."""
     p = _params(20, 11, scale=scale)
     enc, dec = _inputs(512, 512, 96, 3)
-    net = Seq2SeqLSTM(p)
+    net = Seq2SeqLSTM(p, precision=precision)
     got = net.forward(torch.from_numpy(enc).cuda(), torch.from_numpy(dec).cuda())["logits"].cpu().numpy()
     want, _ = R.seq2seq_forward(enc, dec, p, np.float64)
     f32, _ = R.seq2seq_forward(enc, dec, p, np.float32)
@@ -115,6 +118,13 @@ def test_reference_shaped_run_and_literal_ber(cuda_device, capsys):
 def test_errors_and_empty_batches(cuda_device):
     with pytest.raises(nnviterbi_amd.NNViterbiError):
         Seq2SeqLSTM(_params(23, 0))                      # no instantiation beyond 22 hidden units
+    big = _params(8, 0)
+    big["enc_kernel"][2, 3] = 50000.0                    # x 2 log2(e) leaves the f16 range: f16x3 refuses, f32 does not
+    with pytest.raises(nnviterbi_amd.NNViterbiError):
+        Seq2SeqLSTM(big, precision="f16x3")
+    Seq2SeqLSTM(big).close()
+    with pytest.raises(ValueError):
+        Seq2SeqLSTM(_params(8, 0), precision="bf16")
     net = Seq2SeqLSTM(_params(8, 0))
     e = torch.empty((6, 0), dtype=torch.float32, device="cuda")
     assert net.forward(e, e)["logits"].shape == (6, 0)

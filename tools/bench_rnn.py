@@ -39,6 +39,15 @@ for _ in range(args.steps):
     r = net.forward(enc, dec, info_bits=info_u8, n_bits=L, counters=counters)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / args.steps
+fast = Seq2SeqLSTM(params, precision="f16x3")
+rf = fast.forward(enc, dec)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(args.steps):
+    rf = fast.forward(enc, dec)
+e1.record(); torch.cuda.synchronize()
+ms_fast = e0.elapsed_time(e1) / args.steps
+fast_dev = float((rf["logits"] - r["logits"]).abs().max().item())
 H = 20
 flop = 2 * (2 * L) * 2 * (1 + H) * 4 * H + 2 * (2 * L) * H          # both cells' kernels + the projection
 m = 2048
@@ -59,5 +68,7 @@ print(json.dumps({
                                f"matmuls; BLAS decides how many of the cores it uses)"},
     "parity_sample": {"blocks": m, "max_abs_logit_error_vs_float64": err,
                       "cpu_fp32_error_vs_float64": float(np.abs(ref - ref64).max())},
+    "fast_mode": {"dtype": "f16x3", "value": B / (ms_fast * 1e-3), "unit": "blocks/s", "ms_per_step": ms_fast,
+                  "max_abs_logit_difference_from_f32": fast_dev},
     "untrained_sign_decision_ber": float(counters[0].item() / max(counters[2].item(), 1)),
 }))
