@@ -1,0 +1,115 @@
+"""Seeded shape fuzz of the three HIP paths against the oracle (MI355X).
+
+Every case draws a network shape, a row count and inputs from a fixed seed, runs the HIP path in
+both precision modes and applies the stated tolerances of the dedicated suites:
+  K1 / K4 (feed-forward): tanh'd outputs within 1e-5 of the float64 restatement, a class may
+      differ from the float64 argmax only on a float64 near-tie (margin < 1e-5); bits / counters
+      exact functions of the class   (tests/test_gpu_parity.py, tests/test_gpu_wide.py)
+  K5 (recurrent): logits within 5e-5 of the float64 restatement (tests/test_gpu_rnn.py)
+The point is the corners the hand-picked shapes miss: odd input widths, class counts that are not
+multiples of 32, ragged row counts, one-unit layers, class layers straddling the LDS limit."""
+import numpy as np
+import pytest
+import torch
+
+import nnviterbi_amd  # noqa: F401
+from nnviterbi_amd import fnn_viterbi as fv
+from nnviterbi_amd import rnn_viterbi as rv
+from nnviterbi_amd.decoder import PackedMLP, Seq2SeqLSTM, WideMLP
+from oracle import fnn_oracle as O
+from oracle import rnn_oracle as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _net(dims, rng, bias_scale=0.1):
+    Ws = [fv.truncated_normal((dims[i], dims[i + 1]), np.sqrt(2.0 / dims[i]), rng)
+          for i in range(len(dims) - 1)]
+    bs = [(rng.randn(dims[i + 1]) * bias_scale).astype(np.float32) for i in range(len(dims) - 1)]
+    return Ws, bs
+
+
+def _check_ff(cls, act, x, Ws, bs, activation="tanh"):
+    o64 = O.forward(x, Ws, bs, np.float64, activation=activation)
+    assert np.abs(act - o64).max() < TOL
+    c64 = O.argmax_first(o64)
+    bad = cls != c64
+    if bad.any():
+        assert O.top2_margin(o64)[bad].max() < TOL, "class differs on a row that is not a near-tie"
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_decoder_random_shapes(cuda_device, seed, precision):
+    """K1: hidden widths are the first 1..3 of the reference's (128, 64, 32), everything else random."""
+    rng = np.random.RandomState(1000 + seed)
+    n_hidden = rng.randint(1, 4)
+    n_in = int(rng.randint(2, 25))
+    b = int(rng.randint(1, 11))
+    n_classes = int(2 ** b if rng.rand() < 0.5 else rng.randint(2, 2 ** b + 1))
+    dims = [n_in] + [128, 64, 32][:n_hidden] + [n_classes]
+    n = int(rng.choice([1, 2, 31, 33, 63, 64, 65, 500, 2049]))
+    Ws, bs = _net(dims, rng)
+    x = (rng.randn(n, n_in) * 1.3).astype(np.float32)
+    labels = rng.randint(0, n_classes, size=n).astype(np.int32)
+    net = PackedMLP(Ws, bs, precision=precision)
+    xd = torch.from_numpy(x).cuda()
+    r = net.decode(xd, labels=torch.from_numpy(labels).cuda(), tile_bits=b, want_cls64=True, want_bits=True)
+    cls = r["cls32"].cpu().numpy()
+    _check_ff(cls, net.forward(xd).cpu().numpy(), x, Ws, bs)
+    assert np.array_equal(r["cls64"].cpu().numpy(), cls.astype(np.int64))
+    assert np.array_equal(r["bits"].cpu().numpy(), O.class_to_bits(cls, b))
+    assert np.array_equal(r["counters"].cpu().numpy(), O.error_counters(cls, labels, b))
+    net.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_wide_decoder_random_shapes(cuda_device, seed):
+    """K4: 2..6 layers of arbitrary widths, matrix rows or a strided stream, tanh or ReLU."""
+    rng = np.random.RandomState(2000 + seed)
+    depth = int(rng.randint(2, 7))
+    dims = [int(2 * rng.randint(1, 120))] + [int(rng.randint(1, 600)) for _ in range(depth - 1)] + [int(rng.randint(2, 300))]
+    activation = "relu" if seed % 3 == 2 else "tanh"
+    precision = "f16x3" if (seed % 2 == 1 and dims[-1] <= 32) else "f32"
+    if precision == "f16x3" or seed % 4 == 0:
+        dims[-1] = int(rng.randint(2, 33))                 # narrow head kernel
+    n = int(rng.choice([1, 127, 129, 1000, 3001]))
+    Ws, bs = _net(dims, rng)
+    net = WideMLP(Ws, bs, activation=activation, precision=precision)
+    if seed % 2 == 0:                                       # windows of one stream, stride 2
+        stream = rng.randn(2 * (n - 1) + dims[0]).astype(np.float32)
+        x = np.stack([stream[2 * i: 2 * i + dims[0]] for i in range(n)])
+        r = net.decode_stream(torch.from_numpy(stream).cuda(), n, want_act=True)
+    else:
+        x = rng.randn(n, dims[0]).astype(np.float32)
+        r = net.decode(torch.from_numpy(x).cuda(), want_act=True)
+    _check_ff(r["cls32"].cpu().numpy(), r["act"].cpu().numpy(), x, Ws, bs, activation)
+    net.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("seed", range(8))
+def test_recurrent_decoder_random_shapes(cuda_device, seed, precision):
+    """K5: hidden 1..22, independent encoder/decoder lengths (0 allowed for the encoder), ragged batch."""
+    rng = np.random.RandomState(3000 + seed)
+    H = int(rng.randint(1, 23))
+    t_enc, t_dec, batch = int(rng.randint(0, 50)), int(rng.randint(1, 50)), int(rng.randint(1, 200))
+    cfg = rv.RNNDecoderConfig(encoder_hidden_units=H)
+    p = rv.initialize_parameters(cfg, rng=rng)
+    for k in ("enc_bias", "dec_bias", "proj_b"):
+        p[k] = (rng.randn(*p[k].shape) * 0.2).astype(np.float32)
+    enc = np.trunc(rng.randn(t_enc, batch) * 1.5).astype(np.float32)
+    dec = np.sign(rng.randn(t_dec, batch)).astype(np.float32)
+    n_bits = int(rng.randint(1, t_dec + 1))
+    info = (rng.rand(n_bits, batch) > 0.5).astype(np.uint8)
+    net = Seq2SeqLSTM(p, precision=precision)
+    r = net.forward(torch.from_numpy(enc).cuda().reshape(t_enc, batch), torch.from_numpy(dec).cuda(),
+                    info_bits=torch.from_numpy(info).cuda().reshape(n_bits, batch), n_bits=n_bits, want_bits=True)
+    got = r["logits"].cpu().numpy()
+    want, _ = R.seq2seq_forward(enc, dec, p, np.float64)
+    assert np.abs(got - want).max() < 5e-5
+    bits = r["bits"].cpu().numpy()
+    assert np.array_equal(bits, (got[:n_bits] > 0).astype(np.uint8))
+    assert np.array_equal(r["counters"].cpu().numpy(), R.error_counters(bits.T, info.T))
+    net.close()
