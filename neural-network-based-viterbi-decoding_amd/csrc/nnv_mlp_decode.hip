@@ -396,13 +396,41 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     }();
     float best = -__builtin_inff();
     int bidx = 0;
+    // Class-layer M-tiles that are not LDS resident are streamed from L2 as one linear sequence of
+    // "units" (fp32: one fragment group = 4 k-steps; f16x3: one k-step's hi + lo groups), double
+    // buffered in registers: unit u + 1 is requested before the MFMAs of unit u issue, across tile
+    // boundaries too, so the L2 latency sits under 4 (3) MFMAs and the tile's argmax instead of in
+    // front of every load (the compiler's own schedule: load, s_waitcnt vmcnt(0), 4 MFMAs).
+    constexpr int UPT = PREC == kPrecF32 ? KT_OUT * 4 : KT_OUT * 2;  // units per tile (even)
+    constexpr int UNIT_FLOATS = PREC == kPrecF32 ? kFragGroupFloats : 2 * kFragGroupFloats;
+    const int n_units = p.mt_out * UPT;
+    const float *stream = p.wpack + HIDF + lo;
+    u32x4 ubuf[2][PREC == kPrecF32 ? 1 : 2];
+    auto load_unit = [&](int u, int slot) {
+      u = u < n_units ? u : n_units - 1;
+      const u32x4 *src = reinterpret_cast<const u32x4 *>(stream + static_cast<int64_t>(u) * UNIT_FLOATS);
+      ubuf[slot][0] = src[0];
+      if constexpr (PREC != kPrecF32) ubuf[slot][1] = src[kFragGroupFloats / 4];
+    };
+    if (p.out_lds_tiles < p.mt_out) load_unit(p.out_lds_tiles * UPT, 0);
     for (int mt = 0; mt < p.mt_out; ++mt) {
       f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
       if (mt < p.out_lds_tiles) {
         acc = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + mt * KT_OUT * 4 * kFragGroupFloats + lo, acc);
       } else {
-        acc = dense_tile<PREC, KT_OUT>(
-            hlast, p.wpack + HIDF + static_cast<int64_t>(mt) * KT_OUT * 4 * kFragGroupFloats + lo, acc);
+#pragma unroll
+        for (int j = 0; j < UPT; ++j) {
+          load_unit(mt * UPT + j + 1, (j + 1) & 1);
+          if constexpr (PREC == kPrecF32) {
+            const f32x4 a = __builtin_bit_cast(f32x4, ubuf[j & 1][0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma32(a[e], hlast[j / 4].v[4 * (j % 4) + e], acc);
+          } else {
+            acc = mfma16(ubuf[j & 1][1], hlast[j / 2].hi[j % 2], acc);  // small terms first
+            acc = mfma16(ubuf[j & 1][0], hlast[j / 2].lo[j % 2], acc);
+            acc = mfma16(ubuf[j & 1][0], hlast[j / 2].hi[j % 2], acc);
+          }
+        }
       }
       const int cbase = 32 * mt + 4 * half;
       if constexpr (WRITE_ACT) {
