@@ -49,6 +49,7 @@ nnv_status shape_from_desc(const nnv_mlp_desc *net, int32_t precision, PackedSha
   int mts = s->mt_out;
   for (int i = 0; i < s->nhid; ++i) mts += s->mt[i];
   s->bias_floats = 32LL * mts;
+  s->streams = (s->hid_floats + s->out_floats + s->bias_floats) * 4 + nnv::kLdsTailBytes > kLdsLimitBytes ? 1 : 0;
   return nnv::decode_supported(*s);
 }
 

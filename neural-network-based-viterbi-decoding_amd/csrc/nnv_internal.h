@@ -99,6 +99,7 @@ struct PackedShape {
   int64_t hid_floats;   // floats of all hidden-layer groups
   int64_t out_floats;   // floats of the output-layer groups
   int64_t bias_floats;  // 32 * (sum mt + mt_out)
+  int32_t streams;      // 1: the class layer does not fit the LDS beside the rest (streaming kernel)
 };
 
 struct DecodeParams {

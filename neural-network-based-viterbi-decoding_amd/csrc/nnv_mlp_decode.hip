@@ -225,7 +225,9 @@ __device__ unsigned long long g_diag[16];
 #define NNV_STAMP(slot) do {} while (0)
 #endif
 
-template <int PREC, int G1, int NHID, int MTA, int MTB, int MTC, int NT, bool WRITE_ACT>
+// STREAM: the class layer does not fit the LDS; its non-resident M-tiles are streamed from L2.
+// Networks that fit use the STREAM = false instantiation, which carries none of that code.
+template <int PREC, int G1, int NHID, int MTA, int MTB, int MTC, int NT, bool WRITE_ACT, bool STREAM>
 __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // layer 1: fp32 G1 groups of 4 steps (2 inputs each); f16x3 KS1 k-steps of 16 inputs
@@ -242,7 +244,6 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   constexpr int B2OFF = B1OFF + 32 * MTA;
   constexpr int B3OFF = B2OFF + (NHID >= 2 ? 32 * MTB : 0);
   constexpr int BOOFF = B3OFF + (NHID >= 3 ? 32 * MTC : 0);
-  constexpr int WAVES = NT / 64;
 
   const int out_floats = p.mt_out * KT_OUT * 4 * kFragGroupFloats;
   const int bias_floats = (BOOFF - HIDF) + 32 * p.mt_out;
@@ -263,14 +264,12 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       *reinterpret_cast<f32x4 *>(lds + i) = *reinterpret_cast<const f32x4 *>(g_hid + i);
     for (int i = threadIdx.x * 4; i < bias_floats; i += NT * 4)
       *reinterpret_cast<f32x4 *>(lds + HIDF + i) = *reinterpret_cast<const f32x4 *>(g_bias + i);
-    (void)out_floats;
     for (int i = threadIdx.x * 4; i < out_lds_floats; i += NT * 4)
         *reinterpret_cast<f32x4 *>(lds + lds_out + i) = *reinterpret_cast<const f32x4 *>(g_out + i);
   }
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31;
   const int half = lane >> 5;
   // Tiles are dealt to the waves of a workgroup on demand (LDS counter): the
@@ -283,8 +282,6 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     k = __builtin_amdgcn_readfirstlane(k);
     return static_cast<int64_t>(blockIdx.x) + static_cast<int64_t>(k) * gridDim.x;
   };
-  (void)wave;
-  (void)WAVES;
   int64_t tile = grab_tile();
 
   unsigned bit_err = 0, frame_err = 0;
@@ -299,7 +296,6 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   while (tile < p.n_tiles) {
     const int64_t next_tile = grab_tile();
     float xn[XN];
-    bool prefetched = false;
     // The packed weights in LDS never change, so LLVM would hoist every
     // fragment read out of this persistent loop (and spill them).  Making the
     // lane offset opaque once per tile keeps the reads next to their MFMAs.
@@ -349,7 +345,6 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #pragma unroll
       for (int mt = 0; mt < MTA; ++mt) ha[mt].set(layer1_tile(mt));
       if (next_tile < p.n_tiles) load_x<XG>(p, next_tile, j, half, xn);
-      prefetched = true;
       NNV_STAMP(1);
     } else {
       f32x16 acc2[MTB];
@@ -365,14 +360,12 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       }
       NNV_STAMP(1);  // layer 1 + layer 2 MFMAs
       if (next_tile < p.n_tiles) load_x<XG>(p, next_tile, j, half, xn);
-      prefetched = true;
 #pragma unroll
       for (int mt = 0; mt < MTB; ++mt) {
         act16<PREC>(acc2[mt]);
         hb[mt].set(acc2[mt]);
       }
     }
-    (void)prefetched;
 
     NNV_STAMP(2);  // layer 2
     // ---------------- layer 3 ---------------------------------------------
@@ -403,21 +396,22 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     // front of every load (the compiler's own schedule: load, s_waitcnt vmcnt(0), 4 MFMAs).
     constexpr int UPT = PREC == kPrecF32 ? KT_OUT * 4 : KT_OUT * 2;  // units per tile (even)
     constexpr int UNIT_FLOATS = PREC == kPrecF32 ? kFragGroupFloats : 2 * kFragGroupFloats;
-    const int n_units = p.mt_out * UPT;
-    const float *stream = p.wpack + HIDF + lo;
-    u32x4 ubuf[2][PREC == kPrecF32 ? 1 : 2];
+    u32x4 ubuf[STREAM ? 2 : 1][PREC == kPrecF32 ? 1 : 2];
     auto load_unit = [&](int u, int slot) {
+      const int n_units = p.mt_out * UPT;
       u = u < n_units ? u : n_units - 1;
-      const u32x4 *src = reinterpret_cast<const u32x4 *>(stream + static_cast<int64_t>(u) * UNIT_FLOATS);
+      const u32x4 *src = reinterpret_cast<const u32x4 *>(p.wpack + HIDF + lo + static_cast<int64_t>(u) * UNIT_FLOATS);
       ubuf[slot][0] = src[0];
       if constexpr (PREC != kPrecF32) ubuf[slot][1] = src[kFragGroupFloats / 4];
     };
-    if (p.out_lds_tiles < p.mt_out) load_unit(p.out_lds_tiles * UPT, 0);
+    if constexpr (STREAM) {
+      if (p.out_lds_tiles < p.mt_out) load_unit(p.out_lds_tiles * UPT, 0);
+    }
     for (int mt = 0; mt < p.mt_out; ++mt) {
       f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
-      if (mt < p.out_lds_tiles) {
+      if (!STREAM || mt < p.out_lds_tiles) {
         acc = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + mt * KT_OUT * 4 * kFragGroupFloats + lo, acc);
-      } else {
+      } else if constexpr (STREAM) {
 #pragma unroll
         for (int j = 0; j < UPT; ++j) {
           load_unit(mt * UPT + j + 1, (j + 1) & 1);
@@ -558,12 +552,17 @@ using KernelFn = void (*)(const DecodeParams);
 
 struct KernelEntry {
   int prec, g1, nhid, mta, mtb, mtc, nt;
-  bool act;
+  bool act, stream;
   KernelFn fn;
 };
 
-#define NNV_K(P, G1, NHID, A, B, C, NT, ACT) \
-  { P, G1, NHID, A, B, C, NT, ACT, mlp_decode_kernel<P, G1, NHID, A, B, C, NT, ACT> }
+// decode kernels come in a resident and a streaming instantiation; the debug (ACT) ones only streaming
+#define NNV_K1(P, G1, NHID, A, B, C, NT, ACT, ST) \
+  { P, G1, NHID, A, B, C, NT, ACT, ST, mlp_decode_kernel<P, G1, NHID, A, B, C, NT, ACT, ST> }
+#define NNV_K(P, G1, NHID, A, B, C, NT, ACT) NNV_K_##ACT(P, G1, NHID, A, B, C, NT)
+#define NNV_K_false(P, G1, NHID, A, B, C, NT) \
+  NNV_K1(P, G1, NHID, A, B, C, NT, false, true), NNV_K1(P, G1, NHID, A, B, C, NT, false, false)
+#define NNV_K_true(P, G1, NHID, A, B, C, NT) NNV_K1(P, G1, NHID, A, B, C, NT, true, true)
 
 // The reference's networks: hidden widths are the first NHID of (128, 64, 32)
 // (src/fnn_viterbi.py:35-37) = M-tiles (4, 2, 1); n_in = 2b <= 24.
@@ -591,9 +590,10 @@ const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act) {
   const int mta = s.mt[0];
   const int mtb = s.nhid >= 2 ? s.mt[1] : 1;
   const int mtc = s.nhid >= 3 ? s.mt[2] : 1;
+  const bool stream = act || s.streams != 0;
   for (const KernelEntry &k : kKernels)
     if (k.prec == s.precision && k.g1 == s.g1 && k.nhid == s.nhid && k.mta == mta && k.mtb == mtb &&
-        k.mtc == mtc && k.nt == nt && k.act == act)
+        k.mtc == mtc && k.nt == nt && k.act == act && k.stream == stream)
       return &k;
   return nullptr;
 }
