@@ -187,13 +187,13 @@ __device__ __forceinline__ void act16(f32x16 &acc) {
 // apart here; that is far inside the 1e-5 near-tie rule of DESIGN.md.)
 constexpr float kTanhSat = 9.011f;
 
-template <int G1>
+template <int G1, bool VEC_ONLY>
 __device__ __forceinline__ void load_x(const DecodeParams &p, int64_t tile,
                                        int j, int half, float (&xr)[4 * G1]) {
   int64_t row = tile * kRowsPerTile + j;
   row = row < p.n_rows ? row : p.n_rows - 1;  // tail rows: valid memory, discarded
   const float *px = p.x + row * p.n_in + half * p.bp;
-  if (p.xvec) {
+  if (VEC_ONLY || p.xvec) {
 #pragma unroll
     for (int g = 0; g < G1; ++g) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -225,10 +225,18 @@ __device__ unsigned long long g_diag[16];
 #define NNV_STAMP(slot) do {} while (0)
 #endif
 
-// STREAM: the class layer does not fit the LDS; its non-resident M-tiles are streamed from L2.
-// Networks that fit use the STREAM = false instantiation, which carries none of that code.
-template <int PREC, int G1, int NHID, int MTA, int MTB, int MTC, int NT, bool WRITE_ACT, bool STREAM>
+// VARIANT selects what the instantiation carries besides the arithmetic (cold code in the
+// persistent loop costs issue slots and registers even when it is never taken):
+//   kVarGeneral  every option of the ABI, class layer LDS resident
+//   kVarStream   + non-resident class-layer M-tiles streamed from L2
+//   kVarLean     the benchmark / sweep call shape only: 16-byte aligned rows of an even, 4-divisible
+//                half width (p.xvec), class count a multiple of 32, classes + counters out (no
+//                int64 classes, no bit matrix, no per-SNR bins), class layer resident
+constexpr int kVarGeneral = 0, kVarStream = 1, kVarLean = 2;
+template <int PREC, int G1, int NHID, int MTA, int MTB, int MTC, int NT, bool WRITE_ACT, int VARIANT>
 __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
+  constexpr bool STREAM = VARIANT == kVarStream;
+  constexpr bool LEAN = VARIANT == kVarLean;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // layer 1: fp32 G1 groups of 4 steps (2 inputs each); f16x3 KS1 k-steps of 16 inputs
   constexpr int KS1 = (G1 + 1) / 2;
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 
   unsigned bit_err = 0, frame_err = 0;
   float xr[XN];
-  if (tile < p.n_tiles) load_x<XG>(p, tile, j, half, xr);
+  if (tile < p.n_tiles) load_x<XG, LEAN>(p, tile, j, half, xr);
 #ifdef NNV_DIAG
   unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long diag_last = __builtin_amdgcn_s_memtime();
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     if constexpr (NHID == 1) {
 #pragma unroll
       for (int mt = 0; mt < MTA; ++mt) ha[mt].set(layer1_tile(mt));
-      if (next_tile < p.n_tiles) load_x<XG>(p, next_tile, j, half, xn);
+      if (next_tile < p.n_tiles) load_x<XG, LEAN>(p, next_tile, j, half, xn);
       NNV_STAMP(1);
     } else {
       f32x16 acc2[MTB];
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
           acc2[mt] = dense_tile<PREC, 1>(a, lds + W1F + (mt * MTA + kt) * 4 * kFragGroupFloats + lo, acc2[mt]);
       }
       NNV_STAMP(1);  // layer 1 + layer 2 MFMAs
-      if (next_tile < p.n_tiles) load_x<XG>(p, next_tile, j, half, xn);
+      if (next_tile < p.n_tiles) load_x<XG, LEAN>(p, next_tile, j, half, xn);
 #pragma unroll
       for (int mt = 0; mt < MTB; ++mt) {
         act16<PREC>(acc2[mt]);
@@ -404,10 +412,43 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       ubuf[slot][0] = src[0];
       if constexpr (PREC != kPrecF32) ubuf[slot][1] = src[kFragGroupFloats / 4];
     };
+    // First maximum of this lane's 16 classes in ~51 VALU ops: the tile maximum by a
+    // v_max3 tree on the RAW pre-activations, clamped once (clamping is monotone, so
+    // clamp(max z) == max clamp(z)); then the smallest register index r with
+    // z_r >= m (equivalent to clamp(z_r) == m because m <= +sat; below -sat nothing
+    // matches and the tile's first class stands for the all-equal tile), by a
+    // descending select scan; then strict > against the earlier M-tiles (lower class indices).
+    auto argmax_tile = [&](const f32x16 &acc, int mt) {
+      float m = __builtin_fmaxf(acc[0], acc[1]);
+#pragma unroll
+      for (int r = 2; r < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, acc[r]), acc[r + 1]);
+      m = __builtin_amdgcn_fmed3f(m, -kTanhSat, kTanhSat);
+      unsigned t = 16u;
+#pragma unroll
+      for (int r = 15; r >= 0; --r) t = acc[r] >= m ? static_cast<unsigned>(r) : t;
+      t = t == 16u ? 0u : t;
+      const bool c = m > best;
+      best = c ? m : best;
+      bidx = c ? 32 * mt + 4 * half + 8 * static_cast<int>(t >> 2) + static_cast<int>(t & 3u) : bidx;
+    };
+    int mt0 = 0;
+    if constexpr (LEAN) {
+      // two class tiles per iteration: the second tile's MFMAs are independent of the first
+      // tile's argmax, so the scheduler can issue them around it (in f16x3 the matrix pipe
+      // then works under the argmax VALU stream instead of before it)
+      for (; mt0 + 1 < p.mt_out; mt0 += 2) {
+        f32x16 acc_a = init_acc(lds + BOOFF + 32 * mt0, half);
+        f32x16 acc_b = init_acc(lds + BOOFF + 32 * (mt0 + 1), half);
+        acc_a = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + mt0 * KT_OUT * 4 * kFragGroupFloats + lo, acc_a);
+        acc_b = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + (mt0 + 1) * KT_OUT * 4 * kFragGroupFloats + lo, acc_b);
+        argmax_tile(acc_a, mt0);
+        argmax_tile(acc_b, mt0 + 1);
+      }
+    }
     if constexpr (STREAM) {
       if (p.out_lds_tiles < p.mt_out) load_unit(p.out_lds_tiles * UPT, 0);
     }
-    for (int mt = 0; mt < p.mt_out; ++mt) {
+    for (int mt = mt0; mt < p.mt_out; ++mt) {
       f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
       if (!STREAM || mt < p.out_lds_tiles) {
         acc = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + mt * KT_OUT * 4 * kFragGroupFloats + lo, acc);
@@ -436,24 +477,8 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
           }
         }
       }
-      if (((mt + 1) * 32) <= p.n_classes) {
-        // First maximum of this lane's 16 classes in ~51 VALU ops: the tile maximum by a
-        // v_max3 tree on the RAW pre-activations, clamped once (clamping is monotone, so
-        // clamp(max z) == max clamp(z)); then the smallest register index r with
-        // z_r >= m (equivalent to clamp(z_r) == m because m <= +sat; below -sat nothing
-        // matches and the tile's first class stands for the all-equal tile), by a
-        // v_min3 tree; then strict > against the earlier M-tiles (lower class indices).
-        float m = __builtin_fmaxf(acc[0], acc[1]);
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, acc[r]), acc[r + 1]);
-        m = __builtin_amdgcn_fmed3f(m, -kTanhSat, kTanhSat);
-        unsigned t = 16u;
-#pragma unroll
-        for (int r = 15; r >= 0; --r) t = acc[r] >= m ? static_cast<unsigned>(r) : t;
-        t = t == 16u ? 0u : t;
-        const bool c = m > best;
-        best = c ? m : best;
-        bidx = c ? cbase + 8 * static_cast<int>(t >> 2) + static_cast<int>(t & 3u) : bidx;
+      if (LEAN || ((mt + 1) * 32) <= p.n_classes) {
+        argmax_tile(acc, mt);
       } else {  // last tile of a class count that is not a multiple of 32
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -476,15 +501,15 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     }
     if (half == 0 && row < p.n_rows) {
       if (p.cls32) p.cls32[row] = bidx;
-      if (p.cls64) p.cls64[row] = bidx;
-      if (p.bits) {
+      if (!LEAN && p.cls64) p.cls64[row] = bidx;
+      if (!LEAN && p.bits) {
         uint8_t *pb = p.bits + row * p.tile_bits;
         for (int t = 0; t < p.tile_bits; ++t)
           pb[t] = static_cast<uint8_t>((bidx >> (p.tile_bits - 1 - t)) & 1);
       }
       if (p.labels) {
         const unsigned diff = static_cast<unsigned>(bidx) ^ static_cast<unsigned>(label);
-        if (p.n_bins > 1) {  // per-SNR-bin counters (mixed-SNR sweep): LDS atomics
+        if (!LEAN && p.n_bins > 1) {  // per-SNR-bin counters (mixed-SNR sweep): LDS atomics
           const int bin = static_cast<int>(((p.first_row + row) / p.rows_per_block) % p.n_bins);
           atomicAdd(bin_ctr + 4 * bin + 0, static_cast<unsigned>(__builtin_popcount(diff)));
           atomicAdd(bin_ctr + 4 * bin + 1, diff != 0u ? 1u : 0u);
@@ -514,7 +539,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #endif
 
   // ---------------- error counters: one atomic pair per wave --------------
-  if (p.counters && p.n_bins > 1) {
+  if (!LEAN && p.counters && p.n_bins > 1) {
     __syncthreads();
     if (threadIdx.x < p.n_bins) {
       const unsigned *c = bin_ctr + 4 * threadIdx.x;
@@ -552,17 +577,19 @@ using KernelFn = void (*)(const DecodeParams);
 
 struct KernelEntry {
   int prec, g1, nhid, mta, mtb, mtc, nt;
-  bool act, stream;
+  bool act;
+  int variant;
   KernelFn fn;
 };
 
-// decode kernels come in a resident and a streaming instantiation; the debug (ACT) ones only streaming
+// decode kernels come in three variants (see the kernel); the debug (ACT) ones only as kVarStream
 #define NNV_K1(P, G1, NHID, A, B, C, NT, ACT, ST) \
   { P, G1, NHID, A, B, C, NT, ACT, ST, mlp_decode_kernel<P, G1, NHID, A, B, C, NT, ACT, ST> }
 #define NNV_K(P, G1, NHID, A, B, C, NT, ACT) NNV_K_##ACT(P, G1, NHID, A, B, C, NT)
-#define NNV_K_false(P, G1, NHID, A, B, C, NT) \
-  NNV_K1(P, G1, NHID, A, B, C, NT, false, true), NNV_K1(P, G1, NHID, A, B, C, NT, false, false)
-#define NNV_K_true(P, G1, NHID, A, B, C, NT) NNV_K1(P, G1, NHID, A, B, C, NT, true, true)
+#define NNV_K_false(P, G1, NHID, A, B, C, NT)                                                         \
+  NNV_K1(P, G1, NHID, A, B, C, NT, false, kVarGeneral), NNV_K1(P, G1, NHID, A, B, C, NT, false, kVarStream), \
+  NNV_K1(P, G1, NHID, A, B, C, NT, false, kVarLean)
+#define NNV_K_true(P, G1, NHID, A, B, C, NT) NNV_K1(P, G1, NHID, A, B, C, NT, true, kVarStream)
 
 // The reference's networks: hidden widths are the first NHID of (128, 64, 32)
 // (src/fnn_viterbi.py:35-37) = M-tiles (4, 2, 1); n_in = 2b <= 24.
@@ -586,14 +613,14 @@ const KernelEntry kKernels[] = {
 #endif
 };
 
-const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act) {
+const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act, bool lean = false) {
   const int mta = s.mt[0];
   const int mtb = s.nhid >= 2 ? s.mt[1] : 1;
   const int mtc = s.nhid >= 3 ? s.mt[2] : 1;
-  const bool stream = act || s.streams != 0;
+  const int variant = (act || s.streams != 0) ? kVarStream : (lean ? kVarLean : kVarGeneral);
   for (const KernelEntry &k : kKernels)
     if (k.prec == s.precision && k.g1 == s.g1 && k.nhid == s.nhid && k.mta == mta && k.mtb == mtb &&
-        k.mtc == mtc && k.nt == nt && k.act == act && k.stream == stream)
+        k.mtc == mtc && k.nt == nt && k.act == act && k.variant == variant)
       return &k;
   return nullptr;
 }
@@ -677,8 +704,8 @@ nnv_status decode_prepare(const PackedShape &s, int num_cus, int lds_limit) {
   LaunchPlan plan;
   const nnv_status st = decode_plan(s, 1 << 20, num_cus, lds_limit, &plan);
   if (st != NNV_OK) return st;
-  for (const bool act : {false, true}) {
-    const KernelEntry *k = find_kernel(s, act ? 512 : plan.threads, act);
+  for (const int which : {0, 1, 2}) {  // decode, debug forward, lean decode
+    const KernelEntry *k = find_kernel(s, which == 1 ? 512 : plan.threads, which == 1, which == 2);
     if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
     const nnv_status e = ensure_lds_optin(k, plan.lds_bytes);
     if (e != NNV_OK) return e;
@@ -690,7 +717,8 @@ nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
                          const LaunchPlan &plan, bool write_act,
                          hipStream_t stream) {
   const int nt = write_act ? 512 : plan.threads;
-  const KernelEntry *k = find_kernel(s, nt, write_act);
+  const bool lean = !write_act && p.xvec && p.n_bins == 1 && !p.bits && !p.cls64 && p.n_classes % 32 == 0;
+  const KernelEntry *k = find_kernel(s, nt, write_act, lean);
   if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
   {
     const nnv_status e = ensure_lds_optin(k, plan.lds_bytes);
