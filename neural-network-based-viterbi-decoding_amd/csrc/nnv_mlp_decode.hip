@@ -29,6 +29,10 @@
 
 #include "nnv_internal.h"
 
+#ifndef NNV_CLASS_GROUP
+#define NNV_CLASS_GROUP 2
+#endif
+
 namespace nnv {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -436,13 +440,16 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       // two class tiles per iteration: the second tile's MFMAs are independent of the first
       // tile's argmax, so the scheduler can issue them around it (in f16x3 the matrix pipe
       // then works under the argmax VALU stream instead of before it)
-      for (; mt0 + 1 < p.mt_out; mt0 += 2) {
-        f32x16 acc_a = init_acc(lds + BOOFF + 32 * mt0, half);
-        f32x16 acc_b = init_acc(lds + BOOFF + 32 * (mt0 + 1), half);
-        acc_a = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + mt0 * KT_OUT * 4 * kFragGroupFloats + lo, acc_a);
-        acc_b = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + (mt0 + 1) * KT_OUT * 4 * kFragGroupFloats + lo, acc_b);
-        argmax_tile(acc_a, mt0);
-        argmax_tile(acc_b, mt0 + 1);
+      constexpr int kGroup = NNV_CLASS_GROUP;
+      for (; mt0 + kGroup - 1 < p.mt_out; mt0 += kGroup) {
+        f32x16 accs[kGroup];
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i) {
+          accs[i] = init_acc(lds + BOOFF + 32 * (mt0 + i), half);
+          accs[i] = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + (mt0 + i) * KT_OUT * 4 * kFragGroupFloats + lo, accs[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i) argmax_tile(accs[i], mt0 + i);
       }
     }
     if constexpr (STREAM) {
