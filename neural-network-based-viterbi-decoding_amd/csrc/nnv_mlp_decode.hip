@@ -724,7 +724,8 @@ nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
                          const LaunchPlan &plan, bool write_act,
                          hipStream_t stream) {
   const int nt = write_act ? 512 : plan.threads;
-  const bool lean = !write_act && p.xvec && p.n_bins == 1 && !p.bits && !p.cls64 && p.n_classes % 32 == 0;
+  static const bool no_lean = getenv("NNV_NO_LEAN") != nullptr;  // A/B runs only
+  const bool lean = !no_lean && !write_act && p.xvec && p.n_bins == 1 && !p.bits && !p.cls64 && p.n_classes % 32 == 0;
   const KernelEntry *k = find_kernel(s, nt, write_act, lean);
   if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
   {
