@@ -63,14 +63,6 @@ __device__ __forceinline__ float tanh_f32(float z) {
   return __builtin_fmaf(-2.0f, r, 1.0f);
 }
 
-#ifdef NNV_ARGMAX_SALU
-__device__ __forceinline__ unsigned shl1_carry(unsigned t, uint64_t lane_mask) {
-  unsigned r;
-  asm("v_addc_co_u32 %0, vcc, %1, %1, %2" : "=v"(r) : "v"(t), "s"(lane_mask) : "vcc");
-  return r;
-}
-#endif
-
 __device__ __forceinline__ f32x4 load_a(const float *p) {
   return *reinterpret_cast<const f32x4 *>(p);
 }
@@ -94,20 +86,12 @@ __device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo) {
   for (int q = 0; q < 4; ++q) {
     const f32x2 x = {v[2 * q], v[2 * q + 1]};
     const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
-#ifdef NNV_SPLIT_MIXLO
-    unsigned l;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x[0]));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x[1]));
-    hi[q] = h;
-    lo[q] = l;
-#else
     float r0, r1;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x[0]));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x[1]));
     const f32x2 r = {r0, r1};
     hi[q] = h;
     lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-#endif
   }
 }
 
@@ -443,27 +427,6 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #pragma unroll
       for (int r = 2; r < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, acc[r]), acc[r + 1]);
       m = __builtin_amdgcn_fmed3f(m, -kTanhSat, kTanhSat);
-#ifdef NNV_ARGMAX_SALU
-      uint64_t seen = 0, b0 = 0, b1 = 0, b3 = 0, b4 = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint64_t hit = __builtin_amdgcn_ballot_w64(acc[r] >= m);
-        const uint64_t first = hit & ~seen;
-        seen |= hit;
-        if (r & 1) b0 |= first;
-        if (r & 2) b1 |= first;
-        if (r & 4) b3 |= first;
-        if (r & 8) b4 |= first;
-      }
-      unsigned off = shl1_carry(0u, b4);
-      off = shl1_carry(off, b3);
-      off = shl1_carry(off, 0xffffffff00000000ull);
-      off = shl1_carry(off, b1);
-      off = shl1_carry(off, b0);
-      const bool c = m > best;
-      best = c ? m : best;
-      bidx = c ? 32 * mt + static_cast<int>(off) : bidx;
-#else
       unsigned t = 16u;
 #pragma unroll
       for (int r = 15; r >= 0; --r) t = acc[r] >= m ? static_cast<unsigned>(r) : t;
@@ -471,7 +434,6 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       const bool c = m > best;
       best = c ? m : best;
       bidx = c ? 32 * mt + 4 * half + 8 * static_cast<int>(t >> 2) + static_cast<int>(t & 3u) : bidx;
-#endif
     };
     int mt0 = 0;
     if constexpr (LEAN) {
