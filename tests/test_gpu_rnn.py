@@ -136,3 +136,17 @@ def test_errors_and_empty_batches(cuda_device):
     with pytest.raises(nnviterbi_amd.NNViterbiError):     # more hard bits than decoder steps
         net.forward(x, x, info_bits=torch.zeros((9, 4), dtype=torch.uint8, device="cuda"), n_bits=9)
     net.close()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("name", ["h20_l16", "h7_l10"])
+def test_committed_fixture(cuda_device, name, precision):
+    """tests/golden/rnn_fp64.npz: feeds built by the mirrored generators, float64 logits by the oracle."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rnn_fp64.npz"), allow_pickle=False)
+    p = {k: g[f"{name}_{k}"] for k in ("enc_kernel", "enc_bias", "dec_kernel", "dec_bias", "proj_w", "proj_b")}
+    net = Seq2SeqLSTM(p, precision=precision)
+    enc, dec = (torch.from_numpy(np.ascontiguousarray(g[f"{name}_{k}"])).cuda() for k in ("enc", "dec"))
+    got = net.forward(enc, dec)["logits"]
+    assert np.abs(got.cpu().numpy() - g[f"{name}_logits64"]).max() < TOL
+    net.close()

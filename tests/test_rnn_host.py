@@ -139,3 +139,13 @@ def test_forward_fails_loudly_without_a_device():
     feeds = rv.prepare_batch(np.ones((2, 6), np.float32), np.ones((2, 12), np.int32), cfg)
     with pytest.raises(nnviterbi_amd.NNViterbiError):
         rv.run_seq2seq(model, feeds)
+
+
+def test_oracle_reproduces_its_committed_fixture():
+    """tests/golden/rnn_fp64.npz (made by make_rnn_golden.py): the oracle has not drifted."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rnn_fp64.npz"), allow_pickle=False)
+    for name in ("h20_l16", "h7_l10"):
+        p = {k: g[f"{name}_{k}"] for k in ("enc_kernel", "enc_bias", "dec_kernel", "dec_bias", "proj_w", "proj_b")}
+        got, pred = R.seq2seq_forward(g[f"{name}_enc"], g[f"{name}_dec"], p, np.float64)
+        assert np.abs(got - g[f"{name}_logits64"]).max() < 1e-13 and not pred.any()
