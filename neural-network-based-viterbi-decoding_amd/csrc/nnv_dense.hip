@@ -38,7 +38,8 @@ __device__ __forceinline__ float dense_tanh_f32(float z) {
 }
 
 // BK = 32 (row stride 36 floats) or 64 (68): both strides make every b128 access conflict free.
-template <bool GATHER, int kBK>
+// ACT: 1 tanh, 2 relu (compile time: a run-time switch became three scalar branches per value)
+template <bool GATHER, int kBK, int ACT>
 __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
   constexpr int kLdsStride = kBK + 4;
   constexpr int kPasses = kBK / 8;          // float4 loads per thread per operand per k-tile
@@ -175,8 +176,8 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
       for (int r = 0; r < 16; ++r) {
         const int lrow = (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;  // 0..63
         float v = acc[a][b][r] + bias;
-        if (p.act == 1) v = dense_tanh_f32(v);
-        else if (p.act == 2) v = v > 0.f ? v : 0.f;
+        if constexpr (ACT == 1) v = dense_tanh_f32(v);
+        else if constexpr (ACT == 2) v = v > 0.f ? v : 0.f;
         stage[lrow * kOutStride + lcol] = v;
       }
     }
@@ -236,12 +237,19 @@ nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream) {
   // BK = 64 measured 6 % slower than BK = 32 on the 512x512 layers (more staging registers and LDS,
   // same MFMA count); kept as an instantiation for A/B runs only.
   static const bool use64 = getenv("NNV_DENSE_BK64") != nullptr;
-  if (gather)  // layer 1: raw rows, K padded to 32
-    hipLaunchKernelGGL((dense_tanh_kernel<true, 32>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
-  else if (p.Kpad % 64 == 0 && use64)
-    hipLaunchKernelGGL((dense_tanh_kernel<false, 64>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
-  else
-    hipLaunchKernelGGL((dense_tanh_kernel<false, 32>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  if (p.act != 1 && p.act != 2) return NNV_ERR_INVALID_ARGUMENT;
+  const bool tanh_act = p.act == 1;
+  if (gather) {  // layer 1: raw rows, K padded to 32
+    if (tanh_act) hipLaunchKernelGGL((dense_tanh_kernel<true, 32, 1>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((dense_tanh_kernel<true, 32, 2>), grid, block, 0, stream, p);
+  } else if (p.Kpad % 64 == 0 && use64) {
+    if (tanh_act) hipLaunchKernelGGL((dense_tanh_kernel<false, 64, 1>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((dense_tanh_kernel<false, 64, 2>), grid, block, 0, stream, p);
+  } else {
+    if (tanh_act) hipLaunchKernelGGL((dense_tanh_kernel<false, 32, 1>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((dense_tanh_kernel<false, 32, 2>), grid, block, 0, stream, p);
+  }
   return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 
