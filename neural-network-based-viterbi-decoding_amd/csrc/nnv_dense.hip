@@ -29,7 +29,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
-constexpr int kBM = kDenseBM, kBN = kDenseBN;
+constexpr int kBM = kDenseBM;
 
 __device__ __forceinline__ float dense_tanh_f32(float z) {
   const float e = __builtin_amdgcn_exp2f(z * 2.8853900817779268f);
@@ -39,10 +39,18 @@ __device__ __forceinline__ float dense_tanh_f32(float z) {
 
 // BK = 32 (row stride 36 floats) or 64 (68): both strides make every b128 access conflict free.
 // ACT: 1 tanh, 2 relu (compile time: a run-time switch became three scalar branches per value)
-template <bool GATHER, int kBK, int ACT>
+// BN: output columns per block.  128 (2 x 2 waves of 64 x 64) for wide layers; 32 (4 x 1 waves of
+// 32 x 32, BK = 32 only) for NARROW layers such as the bit-wise decoder's 1036 -> 30: those are
+// HBM-shaped (4 KB of row in for 62 kFLOP), and padding 30 outputs to a 128-wide tile made them
+// MFMA-bound at 0.21 of the HBM roofline.
+template <bool GATHER, int kBK, int ACT, int BN>
 __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
+  static_assert(BN == 128 || (BN == 32 && kBK == 32), "tile shapes");
+  constexpr int kBN = BN;                   // shadows the namespace constant inside this kernel
+  constexpr int WT = BN == 128 ? 2 : 1;     // 32 x 32 MFMA tiles per wave, per dimension
   constexpr int kLdsStride = kBK + 4;
-  constexpr int kPasses = kBK / 8;          // float4 loads per thread per operand per k-tile
+  constexpr int kPasses = kBK / 8;          // float4 loads per thread per k-tile of A (128 rows)
+  constexpr int kPassesW = BN == 128 ? kPasses : 1;  // ... of W (BN rows)
   constexpr int kRowsPerPass = 1024 / kBK;  // 32 (BK 32) or 16 (BK 64)
   __shared__ __attribute__((aligned(16))) float lds_all[(kBM + kBN) * kLdsStride];
   float *const lds_a = lds_all;
@@ -69,7 +77,7 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
   // global -> register staging: 128 rows x 32 k = 1024 float4, 4 per thread
   const int ld_row = tid / (kBK / 4);        // + kRowsPerPass per pass
   const int ld_kq = (tid % (kBK / 4)) * 4;   // 0, 4, .., BK-4
-  f32x4 ra[kPasses], rw[kPasses];
+  f32x4 ra[kPasses], rw[kPassesW];
 
   auto load_tiles = [&](int kt) {
     const int k = kt * kBK + ld_kq;
@@ -103,26 +111,30 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
       } else {
         ra[ps] = *reinterpret_cast<const f32x4 *>(src);  // activations: [rows][Kpad], 16-byte aligned
       }
-      rw[ps] = *reinterpret_cast<const f32x4 *>(p.Wt + static_cast<int64_t>(col0 + ld_row + kRowsPerPass * ps) * p.Kpad + k);
+      if (ps < kPassesW)
+        rw[ps] = *reinterpret_cast<const f32x4 *>(p.Wt + static_cast<int64_t>(col0 + ld_row + kRowsPerPass * ps) * p.Kpad + k);
     }
   };
   auto store_tiles = [&]() {
 #pragma unroll
     for (int ps = 0; ps < kPasses; ++ps) {
       *reinterpret_cast<f32x4 *>(lds_a + (ld_row + kRowsPerPass * ps) * kLdsStride + ld_kq) = ra[ps];
-      *reinterpret_cast<f32x4 *>(lds_w + (ld_row + kRowsPerPass * ps) * kLdsStride + ld_kq) = rw[ps];
+      if (ps < kPassesW)
+        *reinterpret_cast<f32x4 *>(lds_w + (ld_row + kRowsPerPass * ps) * kLdsStride + ld_kq) = rw[ps];
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[WT][WT];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < WT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < WT; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  // wave grid: 2 x 2 waves of 64 x 64 (BN 128) or 4 x 1 waves of 32 x 32 (BN 32)
+  const int wrow = BN == 128 ? (wave >> 1) : wave;   // wave's row group
+  const int wr = wrow * 32 * WT, wc = BN == 128 ? (wave & 1) * 64 : 0;
   const int nk = p.Kpad / kBK;
   load_tiles(0);
   for (int kt = 0; kt < nk; ++kt) {
@@ -131,10 +143,10 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
     __syncthreads();
     if (kt + 1 < nk) load_tiles(kt + 1);
     // software pipeline: group g + 1's fragments are read while group g's 16 MFMAs issue
-    f32x4 fa[2][2], fb[2][2];
+    f32x4 fa[2][WT], fb[2][WT];
     auto read_frags = [&](int g, int buf) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < WT; ++t) {
         fa[buf][t] = *reinterpret_cast<const f32x4 *>(lds_a + (wr + 32 * t + li) * kLdsStride + 8 * g + 4 * lh);
         fb[buf][t] = *reinterpret_cast<const f32x4 *>(lds_w + (wc + 32 * t + li) * kLdsStride + 8 * g + 4 * lh);
       }
@@ -146,11 +158,11 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < WT; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
+          for (int b = 0; b < WT; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][a][e], fb[g & 1][b][e], acc[a][b], 0, 0, 0);
-      if (g + 1 < kBK / 8) {
+      if (BN == 128 && g + 1 < kBK / 8) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one ds_read
@@ -168,18 +180,20 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
   // lane halves of one ds_write_b32 (rows 4 apart) land 32 banks apart -> conflict free; so are
   // the 16-byte reads.
   constexpr int kOutStride = kBN + 8;
-  static_assert(64 * kOutStride <= (kBM + kBN) * kLdsStride, "output staging must fit the operand tiles");
+  constexpr int kStageRows = (BN == 128 ? 2 : 4) * 32;   // one register tile `a` of every wave row group
+  static_assert(kStageRows * kOutStride <= (kBM + kBN) * kLdsStride, "output staging must fit the operand tiles");
+  constexpr int kChunksPerRow = kBN / 4;                  // 16-byte chunks per staged row
   float *const stage = lds_all;
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
+  for (int a = 0; a < WT; ++a) {
     __syncthreads();  // operand tiles (a = 0) / previous half (a = 1) fully consumed
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < WT; ++b) {
       const int lcol = wc + 32 * b + li;
       const float bias = p.bias[col0 + lcol];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int lrow = (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;  // 0..63
+        const int lrow = wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         float v = acc[a][b][r] + bias;
         if constexpr (ACT == 1) v = dense_tanh_f32(v);
         else if constexpr (ACT == 2) v = v > 0.f ? v : 0.f;
@@ -188,10 +202,10 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < (64 * kBN / 4) / 256; ++it) {
-      const int chunk = tid + 256 * it;  // 32 chunks of 16 B per staged row
-      const int lrow = chunk >> 5, c4 = (chunk & 31) * 4;
-      const int64_t row = row0 + (lrow >> 5) * 64 + 32 * a + (lrow & 31);
+    for (int it = 0; it < (kStageRows * kChunksPerRow) / 256; ++it) {
+      const int chunk = tid + 256 * it;
+      const int lrow = chunk / kChunksPerRow, c4 = (chunk % kChunksPerRow) * 4;
+      const int64_t row = row0 + (lrow >> 5) * 32 * WT + 32 * a + (lrow & 31);
       if (row < p.n_rows)
         *reinterpret_cast<f32x4 *>(p.C + row * p.ldc + col0 + c4) =
             *reinterpret_cast<const f32x4 *>(stage + lrow * kOutStride + c4);
@@ -244,17 +258,24 @@ nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream) {
   static const bool use64 = getenv("NNV_DENSE_BK64") != nullptr;
   const dim3 grid(static_cast<unsigned>(blocks)), block(256);
   if (p.act != 1 && p.act != 2) return NNV_ERR_INVALID_ARGUMENT;
+  if (p.bn != 128 && p.bn != 32) return NNV_ERR_INVALID_ARGUMENT;
   const bool tanh_act = p.act == 1;
-  if (gather) {  // layer 1: raw rows, K padded to 32
-    if (tanh_act) hipLaunchKernelGGL((dense_tanh_kernel<true, 32, 1>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((dense_tanh_kernel<true, 32, 2>), grid, block, 0, stream, p);
+#define NNV_DENSE_LAUNCH(G, BK, BNV)                                                              \
+  do {                                                                                            \
+    if (tanh_act) hipLaunchKernelGGL((dense_tanh_kernel<G, BK, 1, BNV>), grid, block, 0, stream, p); \
+    else hipLaunchKernelGGL((dense_tanh_kernel<G, BK, 2, BNV>), grid, block, 0, stream, p);          \
+  } while (0)
+  if (p.bn == 32) {  // narrow layer
+    if (gather) NNV_DENSE_LAUNCH(true, 32, 32);
+    else NNV_DENSE_LAUNCH(false, 32, 32);
+  } else if (gather) {  // layer 1: raw rows, K padded to 32
+    NNV_DENSE_LAUNCH(true, 32, 128);
   } else if (p.Kpad % 64 == 0 && use64) {
-    if (tanh_act) hipLaunchKernelGGL((dense_tanh_kernel<false, 64, 1>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((dense_tanh_kernel<false, 64, 2>), grid, block, 0, stream, p);
+    NNV_DENSE_LAUNCH(false, 64, 128);
   } else {
-    if (tanh_act) hipLaunchKernelGGL((dense_tanh_kernel<false, 32, 1>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((dense_tanh_kernel<false, 32, 2>), grid, block, 0, stream, p);
+    NNV_DENSE_LAUNCH(false, 32, 128);
   }
+#undef NNV_DENSE_LAUNCH
   return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 

@@ -161,9 +161,10 @@ struct DenseParams {
   const float *bias;     // [Mpad]
   float *C;              // [n_rows][ldc]
   int64_t ldc;
-  int32_t nblk_m;        // Mpad / 128
+  int32_t nblk_m;        // Mpad / bn
   int64_t nblk_rows;     // ceil(n_rows / 128)
-  int32_t act;           // 0 none, 1 tanh, 2 relu
+  int32_t act;           // 1 tanh, 2 relu
+  int32_t bn;            // output columns per block: 128, or 32 for narrow layers
 };
 struct HeadParams {
   const float *A;        // [n_rows][lda]

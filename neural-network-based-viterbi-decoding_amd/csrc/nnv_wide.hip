@@ -10,7 +10,8 @@ struct nnv_wide_handle {
   int32_t depth;
   int32_t dims[NNV_WIDE_MAX_LAYERS + 1];
   int32_t kpad[NNV_WIDE_MAX_LAYERS];  // padded input width of layer l (multiple of 32)
-  int32_t mpad[NNV_WIDE_MAX_LAYERS];  // padded output width (multiple of 128; class layer: see head)
+  int32_t mpad[NNV_WIDE_MAX_LAYERS];  // padded output width (multiple of bn[l]; class layer: see head)
+  int32_t bn[NNV_WIDE_MAX_LAYERS];    // GEMM column tile of layer l: 128, or 32 for narrow fp32 layers
   int32_t head;                       // 1: the class layer runs in head_argmax_kernel (<= 32 classes)
   int32_t act;                        // 1 tanh, 2 relu
   int32_t f16x3;                      // 1: hidden layers' weights are hi/lo f16 planes (w_off = hi, wl_off = lo, in halves)
@@ -99,7 +100,9 @@ int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out) {
     const bool is_head = h->head && l == net->depth - 1;
     // layer l reads the previous layer's padded output (or the raw rows for l = 0)
     h->kpad[l] = l == 0 ? round_up(net->dims[0], nnv::kDenseBK) : h->mpad[l - 1];
-    h->mpad[l] = is_head ? net->dims[l + 1] : round_up(net->dims[l + 1], nnv::kDenseBN);
+    // narrow fp32 layers (<= 64 outputs, e.g. the bit-wise decoder's 30) use 32-column tiles
+    h->bn[l] = (!h->f16x3 && net->dims[l + 1] <= 64) ? 32 : nnv::kDenseBN;
+    h->mpad[l] = is_head ? net->dims[l + 1] : round_up(net->dims[l + 1], h->bn[l]);
     if (!is_head && h->mpad[l] > h->max_mpad) h->max_mpad = h->mpad[l];
     h->w_off[l] = total;   // fp32: [mpad][kpad] floats; f16x3 hidden layer: hi plane then lo plane (same bytes)
     total += static_cast<int64_t>(h->mpad[l]) * h->kpad[l];
@@ -253,7 +256,8 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev, int64_
       dp.bias = h->dev + h->b_off[l];
       dp.C = buf[cur];
       dp.ldc = h->mpad[l];
-      dp.nblk_m = h->mpad[l] / nnv::kDenseBN;
+      dp.bn = h->bn[l];
+      dp.nblk_m = h->mpad[l] / h->bn[l];
       dp.nblk_rows = (rows + nnv::kDenseBM - 1) / nnv::kDenseBM;
       dp.act = h->act;
       const nnv_status st = nnv::dense_launch(dp, l == 0, s);
