@@ -560,3 +560,15 @@ def _(x, weights, biases, tile_bits, labels=None):
     n = x.shape[0]
     return (x.new_empty((n,), dtype=torch.int64), x.new_empty((n, tile_bits), dtype=torch.uint8),
             x.new_empty((4,), dtype=torch.int64))
+
+
+@torch.library.custom_op("nnviterbi::mlp_forward", mutates_args=(), device_types="cuda")
+def mlp_forward(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.Tensor]) -> torch.Tensor:
+    """multilayer_perceptron(x, weights, biases) (src/fnn_viterbi.py:471-510): the tanh'd class layer
+    [N, n_classes] float32 — debug / parity op, HIP only."""
+    return _cached_pack(list(weights), list(biases), x.device).forward(x)
+
+
+@mlp_forward.register_fake
+def _(x, weights, biases):
+    return x.new_empty((x.shape[0], biases[-1].shape[0]), dtype=torch.float32)

@@ -517,3 +517,5 @@ def test_torch_custom_op(cuda_device):
     assert np.array_equal(counters.cpu().numpy(), O.error_counters(c, labels, b))
     with pytest.raises(Exception):
         torch.ops.nnviterbi.mlp_decode(torch.from_numpy(x), tw, tb, b, None)   # CPU tensor: no kernel
+    out = torch.ops.nnviterbi.mlp_forward(torch.from_numpy(x).cuda(), tw, tb)
+    assert out.shape == (n, 256) and np.abs(out.cpu().numpy() - O.forward(x, Ws, bs, np.float64)).max() < TOL
