@@ -7,6 +7,38 @@ derived per-tile figures DESIGN.md quotes.  Also rewrites profiles/pmc_traffic.j
 import csv, glob, json, os, sys
 from collections import defaultdict
 
+if len(sys.argv) > 1 and sys.argv[1] == "--secondary":
+    # per-kernel per-launch means of every counter for the K4 / K5 kernels (tools/profile_secondary.sh)
+    root = sys.argv[2]
+    out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "pmc_secondary.json")
+    acc2 = defaultdict(lambda: defaultdict(list))
+    for path in glob.glob(os.path.join(root, "pmc2_*", "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for r in csv.DictReader(f):
+                name = r["Kernel_Name"]
+                if not any(k in name for k in ("dense_tanh_kernel", "dense_f16x3_kernel", "head_argmax", "seq2seq_kernel")):
+                    continue
+                if int(r["Grid_Size"]) < 256 * 1024:     # skip the warm-up / tail launches over tiny chunks
+                    continue
+                acc2[name.replace("void nnv::", "").replace("(anonymous namespace)::", "").split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {"source_dir": root, "note": "per-launch means over full-size launches; FETCH_SIZE/WRITE_SIZE in KB "
+           "(FETCH_SIZE x2 for wide coalesced streams on gfx950, MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over 8 XCDs",
+           "kernels": {}}
+    for name, ctrs in sorted(acc2.items()):
+        k = {n: {"per_launch_mean": sum(v) / len(v), "launches": len(v)} for n, v in sorted(ctrs.items())}
+        g = lambda n: k.get(n, {}).get("per_launch_mean")
+        d = {"counters": k}
+        if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+            d["hbm_read_bytes_per_launch_x2_corrected"] = g("FETCH_SIZE") * 2048
+            d["hbm_write_bytes_per_launch"] = g("WRITE_SIZE") * 1024
+        if g("GRBM_GUI_ACTIVE") and g("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+            d["mfma_busy_frac_per_simd"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / (g("GRBM_GUI_ACTIVE") / 8)
+        res["kernels"][name] = d
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+    print("wrote", out_path)
+    sys.exit(0)
+
 root = sys.argv[1]
 out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "pmc_summary.json")
 ROWS = 80_000_000
