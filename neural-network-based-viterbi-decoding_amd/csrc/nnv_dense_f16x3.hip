@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void dense_f16x3_kernel(const DenseF16Params p
   constexpr int kChunks = kPlane / 16;      // 16-byte chunks per plane segment (4 or 8)
   constexpr int kRowsPerPass = 256 / kChunks;
   constexpr int kPasses = 128 / kRowsPerPass;
-  constexpr int kGPasses = BK / 8;          // gather: float4 loads per thread
-  constexpr int kGRows = 1024 / BK;
+  constexpr int kGPasses = BK / 16;         // gather: 8-float row pieces per thread
+  constexpr int kGRows = 2048 / BK;         // rows covered per pass (BK / 8 threads per row)
   __shared__ __attribute__((aligned(16))) unsigned char lds_all[(kDenseBM + kDenseBN) * kRowBytes];
   unsigned char *const lds_a = lds_all;
   unsigned char *const lds_w = lds_all + kDenseBM * kRowBytes;
@@ -77,8 +77,10 @@ __global__ __launch_bounds__(256) void dense_f16x3_kernel(const DenseF16Params p
   const int st_chunk = tid % kChunks;   // 16-byte chunk (8 halves) of the plane segment
   u32x4 ra[2 * kPasses], rw[2 * kPasses];  // [0, kPasses): hi plane ; [kPasses, 2 kPasses): lo plane
   // gather mode (layer 1): fp32 rows, split while staging
-  const int g_row = tid / (BK / 4), g_kq = (tid % (BK / 4)) * 4;
-  f32x4 ga[kGPasses];
+  // each thread owns 8 consecutive k of one row: its hi and lo halves leave as ONE 16-byte LDS
+  // write each (8-byte writes at the 144-byte row stride collided: 10 % of the layer's cycles)
+  const int g_row = tid / (BK / 8), g_kq = (tid % (BK / 8)) * 8;
+  f32x4 ga[2 * kGPasses];
 
   auto load_tiles = [&](int kt) {
 #pragma unroll
@@ -102,22 +104,26 @@ __global__ __launch_bounds__(256) void dense_f16x3_kernel(const DenseF16Params p
         int64_t r = row0 + g_row + kGRows * ps;
         r = r < p.n_rows ? r : p.n_rows - 1;
         const float *src = p.A_f32 + r * p.a_row_stride + k;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k + 1 < p.K) {
-          const f32x2 t = *reinterpret_cast<const f32x2 *>(src);
-          v[0] = t[0];
-          v[1] = t[1];
-        } else if (k < p.K) {
-          v[0] = src[0];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // rows are only 8-byte aligned and may end inside the tile
+          const int kk = k + 4 * h;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (kk + 1 < p.K) {
+            const f32x2 t = *reinterpret_cast<const f32x2 *>(src + 4 * h);
+            v[0] = t[0];
+            v[1] = t[1];
+          } else if (kk < p.K) {
+            v[0] = src[4 * h];
+          }
+          if (kk + 3 < p.K) {
+            const f32x2 t = *reinterpret_cast<const f32x2 *>(src + 4 * h + 2);
+            v[2] = t[0];
+            v[3] = t[1];
+          } else if (kk + 2 < p.K) {
+            v[2] = src[4 * h + 2];
+          }
+          ga[2 * ps + h] = v;
         }
-        if (k + 3 < p.K) {
-          const f32x2 t = *reinterpret_cast<const f32x2 *>(src + 2);
-          v[2] = t[0];
-          v[3] = t[1];
-        } else if (k + 2 < p.K) {
-          v[2] = src[2];
-        }
-        ga[ps] = v;
       }
     }
   };
@@ -136,13 +142,20 @@ __global__ __launch_bounds__(256) void dense_f16x3_kernel(const DenseF16Params p
     if (GATHER) {
 #pragma unroll
       for (int ps = 0; ps < kGPasses; ++ps) {
-        unsigned h0, l0, h1, l1;
-        split2(ga[ps][0], ga[ps][1], h0, l0);
-        split2(ga[ps][2], ga[ps][3], h1, l1);
-        const u32x2 hi = {h0, h1}, lo = {l0, l1};
+        u32x4 hi, lo;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          unsigned h0, l0, h1, l1;
+          split2(ga[2 * ps + h][0], ga[2 * ps + h][1], h0, l0);
+          split2(ga[2 * ps + h][2], ga[2 * ps + h][3], h1, l1);
+          hi[2 * h] = h0;
+          hi[2 * h + 1] = h1;
+          lo[2 * h] = l0;
+          lo[2 * h + 1] = l1;
+        }
         unsigned char *a = lds_a + (g_row + kGRows * ps) * kRowBytes + g_kq * 2;
-        *reinterpret_cast<u32x2 *>(a) = hi;
-        *reinterpret_cast<u32x2 *>(a + kPlane) = lo;
+        *reinterpret_cast<u32x4 *>(a) = hi;
+        *reinterpret_cast<u32x4 *>(a + kPlane) = lo;
       }
     }
   };
