@@ -1,0 +1,79 @@
+/* The drop-in boundary used from plain C: no Python, no torch.
+ *   gcc -std=c11 -D__HIP_PLATFORM_AMD__ examples/decode_c_abi.c -Iinclude -I/opt/rocm/include \
+ *       -Lneural-network-based-viterbi-decoding_amd -lnnviterbi_hip -L/opt/rocm/lib -lamdhip64 \
+ *       -Wl,-rpath,$PWD/neural-network-based-viterbi-decoding_amd -Wl,-rpath,/opt/rocm/lib -o decode_c_abi
+ * A matched-filter network of the reference's architecture (pass-through hidden layers, class layer =
+ * correlation with every codeword of the (133,171) b = 8 tile code, src/fnn_viterbi.py:157-217) decodes
+ * blocks generated on the device: at sigma = 0 every block must come back exactly; at 2 dB the BER of
+ * the per-tile maximum-likelihood decision is printed.  Exit status 0 = the round trip was exact. */
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "nnviterbi.h"
+
+#define CHECK_HIP(e) do { if ((e) != hipSuccess) { fprintf(stderr, "HIP error line %d\n", __LINE__); return 2; } } while (0)
+#define CHECK_NNV(e) do { int s_ = (e); if (s_ != NNV_OK) { fprintf(stderr, "%s (line %d)\n", nnv_status_string(s_), __LINE__); return 3; } } while (0)
+
+/* zero-state (133,171) encoder, output order g=133 first (taps {0,2,3,5,6} and {0,1,2,3,6}) */
+static void encode_133171(const int *u, int n, int *out) {
+  for (int t = 0; t < n; ++t) {
+#define U(i) ((i) < 0 ? 0 : u[i])
+    out[2 * t] = (U(t) + U(t - 2) + U(t - 3) + U(t - 5) + U(t - 6)) & 1;
+    out[2 * t + 1] = (U(t) + U(t - 1) + U(t - 2) + U(t - 3) + U(t - 6)) & 1;
+#undef U
+  }
+}
+
+int main(void) {
+  enum { B = 8, NIN = 16, C = 256, H1 = 128, H2 = 64, H3 = 32 };
+  const int64_t n_rows = 8 * 1000 * 1000;  /* 1 M blocks of 8 tiles */
+  if (nnv_device_count() < 1) { fprintf(stderr, "no gfx950 device\n"); return 1; }
+
+  /* weights [in][out], the reference's layout (src/fnn_viterbi.py:432-456) */
+  float *W1 = calloc(NIN * H1, 4), *W2 = calloc(H1 * H2, 4), *W3 = calloc(H2 * H3, 4), *W4 = calloc(H3 * C, 4);
+  float *b1 = calloc(H1, 4), *b2 = calloc(H2, 4), *b3 = calloc(H3, 4), *b4 = calloc(C, 4);
+  for (int i = 0; i < NIN; ++i) { W1[i * H1 + i] = 0.05f; W2[i * H2 + i] = 1.0f; W3[i * H3 + i] = 1.0f; }
+  for (int c = 0; c < C; ++c) {
+    int u[B], e[2 * B];
+    for (int t = 0; t < B; ++t) u[t] = (c >> (B - 1 - t)) & 1;  /* MSB first, src/fnn_viterbi.py:281-285 */
+    encode_133171(u, B, e);
+    for (int k = 0; k < NIN; ++k) W4[k * C + c] = e[k] ? 2.0f : -2.0f;
+  }
+  nnv_mlp_desc net;
+  memset(&net, 0, sizeof(net));
+  net.depth = 4;
+  const int dims[5] = {NIN, H1, H2, H3, C};
+  for (int i = 0; i < 5; ++i) net.dims[i] = dims[i];
+  net.W_host[0] = W1; net.W_host[1] = W2; net.W_host[2] = W3; net.W_host[3] = W4;
+  net.b_host[0] = b1; net.b_host[1] = b2; net.b_host[2] = b3; net.b_host[3] = b4;
+  nnv_mlp_handle *h = NULL;
+  CHECK_NNV(nnv_mlp_prepack(&net, &h));
+
+  float *x = NULL;
+  int32_t *labels = NULL, *cls = NULL;
+  uint64_t *counters = NULL, host[4];
+  CHECK_HIP(hipMalloc((void **)&x, n_rows * NIN * sizeof(float)));
+  CHECK_HIP(hipMalloc((void **)&labels, n_rows * sizeof(int32_t)));
+  CHECK_HIP(hipMalloc((void **)&cls, n_rows * sizeof(int32_t)));
+  CHECK_HIP(hipMalloc((void **)&counters, 4 * sizeof(uint64_t)));
+
+  int exact = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const float sigma = pass == 0 ? 0.0f : 0.5616748812614791f;  /* noiseless, then 2 dB */
+    CHECK_HIP(hipMemset(counters, 0, 4 * sizeof(uint64_t)));
+    CHECK_NNV(nnv_awgn_generate_f32(NNV_CODE_133171, B, n_rows, 0, 8, &sigma, 1, 2024, x, labels, NULL));
+    CHECK_NNV(nnv_mlp_decode_f32(h, x, n_rows, B, labels, cls, NULL, NULL, counters, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(host, counters, sizeof(host), hipMemcpyDeviceToHost));
+    printf("sigma %.4f: bit errors %llu / %llu  (BER %.3e), tile errors %llu / %llu\n", sigma,
+           (unsigned long long)host[0], (unsigned long long)host[2], (double)host[0] / (double)host[2],
+           (unsigned long long)host[1], (unsigned long long)host[3]);
+    if (pass == 0) exact = host[0] == 0 && host[1] == 0 && host[2] == (uint64_t)n_rows * B && host[3] == (uint64_t)n_rows;
+  }
+  CHECK_NNV(nnv_mlp_free(h));
+  hipFree(x); hipFree(labels); hipFree(cls); hipFree(counters);
+  return exact ? 0 : 4;
+}

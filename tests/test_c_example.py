@@ -1,0 +1,40 @@
+"""The C ABI from plain C (examples/decode_c_abi.c): the public header compiles as C11, the program
+links against libnnviterbi_hip.so alone (no Python, no torch), and on an MI355X its noiseless round trip
+over 1 M blocks is exact."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "neural-network-based-viterbi-decoding_amd")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+def _build(tmp_path):
+    if shutil.which("gcc") is None or not os.path.exists(os.path.join(PKG, "libnnviterbi_hip.so")):
+        pytest.skip("gcc or the built library is missing")
+    exe = str(tmp_path / "decode_c_abi")
+    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__",
+           os.path.join(ROOT, "examples", "decode_c_abi.c"), "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROCM, "include"), "-L" + PKG, "-lnnviterbi_hip", "-L" + os.path.join(ROCM, "lib"),
+           "-lamdhip64", "-Wl,-rpath," + PKG, "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_c_example_compiles_as_c11(tmp_path):
+    _build(tmp_path)
+
+
+@pytest.mark.gpu
+def test_c_example_round_trip_is_exact(tmp_path, cuda_device):
+    exe = _build(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("sigma 0.0000: bit errors 0 / 64000000") and "tile errors 0 / 8000000" in lines[0]
+    ber = float(lines[1].split("BER ")[1].split(")")[0])
+    assert 1e-3 < ber < 2e-2          # per-tile ML decision of the (133,171) b = 8 tile code at 2 dB
