@@ -519,3 +519,42 @@ def test_torch_custom_op(cuda_device):
         torch.ops.nnviterbi.mlp_decode(torch.from_numpy(x), tw, tb, b, None)   # CPU tensor: no kernel
     out = torch.ops.nnviterbi.mlp_forward(torch.from_numpy(x).cuda(), tw, tb)
     assert out.shape == (n, 256) and np.abs(out.cpu().numpy() - O.forward(x, Ws, bs, np.float64)).max() < TOL
+
+
+def test_concurrent_host_threads_and_streams(cuda_device):
+    """The boundary claims stream-ordered, re-entrant calls with no global state: four
+    host threads, each with its own HIP stream and its own counters, decode different inputs through
+    ONE packed network (and a second network in the other precision) at the same time."""
+    import threading
+    dims, b, n = [16, 128, 64, 32, 256], 8, 200_000
+    Ws, bs = _net(dims, 21)
+    nets = [PackedMLP(Ws, bs, precision="f32"), PackedMLP(Ws, bs, precision="f16x3")]
+    rng = np.random.RandomState(8)
+    xs = [torch.from_numpy((rng.randn(n, 16) * 1.1).astype(np.float32)).cuda() for _ in range(4)]
+    labs = [torch.from_numpy(rng.randint(0, 256, n).astype(np.int32)).cuda() for _ in range(4)]
+    want = [nets[i % 2].decode(xs[i], labels=labs[i], tile_bits=b) for i in range(4)]
+    torch.cuda.synchronize()
+    got, errors = [None] * 4, []
+
+    def worker(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(5):
+                    r = nets[i % 2].decode(xs[i], labels=labs[i], tile_bits=b)
+            s.synchronize()
+            got[i] = r
+        except Exception as e:  # pragma: no cover - surfaced below
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(4):
+        assert torch.equal(got[i]["cls32"], want[i]["cls32"])
+        assert torch.equal(got[i]["counters"], want[i]["counters"])
+    for net in nets:
+        net.close()
