@@ -248,26 +248,36 @@ def train_seq2seq(config: RNNDecoderConfig, train_info: np.ndarray, train_encode
     dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     P = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True)
          for k, v in model["params"].items()}
-    opt = torch.optim.Adam(list(P.values()), lr=config.learning_rate, betas=(0.9, 0.999), eps=1e-8)
+    opt = torch.optim.Adam(list(P.values()), lr=config.learning_rate, betas=(0.9, 0.999), eps=1e-8,
+                           capturable=(dev.type == "cuda"))
     batches_per_epoch = int(config.training_size / config.batch_size)
     max_batches = batches_per_epoch * config.training_epochs
     loss_history = []
+    forget_bias = float(model.get("forget_bias", 1.0))
+
+    def step(enc, dec, tgt):
+        loss = ((tgt - _torch_forward(P, enc, dec, forget_bias)) ** 2).mean()
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    def feeds_of(lo):
+        f = prepare_batch(train_info[lo:lo + config.batch_size], train_encoded[lo:lo + config.batch_size], config)
+        return (torch.as_tensor(_time_major(f["encoder_inputs"]), device=dev),
+                torch.as_tensor(_time_major(f["decoder_inputs"]), device=dev),
+                torch.as_tensor(np.asarray(f["decoder_targets"], np.float32), device=dev))
+
+    # one batch step = 4L cell evaluations = thousands of tiny kernels: captured once, replayed per batch
+    from .training import GraphedStep
+    run = GraphedStep(step, list(P.values()), opt, feeds_of(0), verbose) if max_batches > 0 else step
     if verbose:
         print(f"Training for {config.training_epochs} epochs ({max_batches} batches)...")
     for batch_idx in range(max_batches):
         start = (batch_idx % batches_per_epoch) * config.batch_size
         info_batch = train_info[start:start + config.batch_size]
         encoded_batch = train_encoded[start:start + config.batch_size]
-        feeds = prepare_batch(info_batch, encoded_batch, config)
-        enc = torch.as_tensor(_time_major(feeds["encoder_inputs"]), device=dev)
-        dec = torch.as_tensor(_time_major(feeds["decoder_inputs"]), device=dev)
-        tgt = torch.as_tensor(np.asarray(feeds["decoder_targets"], np.float32), device=dev)
-        logits = _torch_forward(P, enc, dec, float(model.get("forget_bias", 1.0)))
-        loss = ((tgt - logits) ** 2).mean()
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
-        loss_history.append(float(loss.detach()))
+        loss_history.append(float(run(*feeds_of(start))))
         if verbose and batch_idx % batches_per_epoch == 0:
             epoch = batch_idx // batches_per_epoch
             print(f"Epoch {epoch + 1}/{config.training_epochs} | Loss: {loss_history[-1]:.6f}")

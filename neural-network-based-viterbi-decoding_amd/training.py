@@ -29,6 +29,61 @@ def _device():
     return torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
+class GraphedStep:
+    """``step(*inputs) -> scalar cost`` (forward, backward, optimizer update) captured once into a
+    HIP graph and replayed per batch.  The reference's networks are tiny, so an eager step is bound
+    by its kernel launches (the feed-forward trainer: ~25 per step; the recurrent one: thousands).
+    Same kernels in the same order as eager mode; on the CPU, or if capture fails, calls run eagerly.
+
+    ``params``: the leaf tensors the optimizer updates; ``opt`` must have been built with
+    ``capturable=True`` on CUDA; ``example_inputs``: tensors of the batch shapes (copied)."""
+
+    def __init__(self, step, params, opt, example_inputs, verbose: bool = False):
+        self._step = step
+        self._graph = None
+        self._static = None
+        self._cost = None
+        dev = params[0].device
+        if dev.type != "cuda":
+            return
+        try:
+            static = [t.clone() for t in example_inputs]
+            saved = [t.detach().clone() for t in params]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):                       # warm-up steps outside the graph
+                    step(*static)
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.no_grad():                        # undo the warm-up: weights and optimizer state
+                for t, v in zip(params, saved):
+                    t.copy_(v)
+                for st in opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):                    # records, does not execute
+                cost = step(*static)
+            self._graph, self._static, self._cost = g, static, cost
+        except Exception as e:  # pragma: no cover - depends on the runtime
+            if verbose:
+                print(f"(HIP graph capture of the training step unavailable: {e}; eager mode)")
+            self._graph = None
+
+    @property
+    def captured(self) -> bool:
+        return self._graph is not None
+
+    def __call__(self, *inputs):
+        if self._graph is None:
+            return self._step(*inputs)
+        for dst, src in zip(self._static, inputs):
+            dst.copy_(src)
+        self._graph.replay()
+        return self._cost
+
+
 def train_network(config, training_set: np.ndarray, training_labels: np.ndarray,
                   weights: Dict[str, np.ndarray], biases: Dict[str, np.ndarray],
                   use_dropout: bool = False, keep_prob: float = 0.5,
@@ -68,47 +123,12 @@ def train_network(config, training_set: np.ndarray, training_labels: np.ndarray,
         opt.step()
         return cost.detach()
 
-    # On the GPU the whole step (forward, backward, Adam) is captured once into a HIP graph and
-    # replayed per batch: the networks are tiny, so eager mode is bound by ~25 kernel launches per
-    # step (200 epochs of the reference's default set: 41 s eager).  Same kernels, same order, same
-    # numbers; any capture problem falls back to eager.
-    graph = None
-    if dev.type == "cuda" and total_batch > 0:
-        try:
-            xs, ys = x_all[:bs].clone(), y_all[:bs].clone()
-            saved = [t.detach().clone() for t in W + B]
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):                       # warm-up steps outside the graph
-                    step(xs, ys)
-            torch.cuda.current_stream().wait_stream(side)
-            with torch.no_grad():                        # undo the warm-up: weights and Adam state
-                for t, v in zip(W + B, saved):
-                    t.copy_(v)
-                for st in opt.state.values():
-                    for v in st.values():
-                        if torch.is_tensor(v):
-                            v.zero_()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):                    # records, does not execute
-                cost_static = step(xs, ys)
-            graph = g
-        except Exception as e:  # pragma: no cover - depends on the runtime
-            if verbose:
-                print(f"(HIP graph capture of the training step unavailable: {e}; eager mode)")
-            graph = None
+    run = GraphedStep(step, W + B, opt, [x_all[:bs], y_all[:bs]], verbose) if total_batch > 0 else step
 
     for epoch in range(int(config.training_epochs)):
         avg_cost = torch.zeros((), device=dev)
         for i in range(total_batch):
-            if graph is not None:
-                xs.copy_(x_all[i * bs:(i + 1) * bs])
-                ys.copy_(y_all[i * bs:(i + 1) * bs])
-                graph.replay()
-                avg_cost += cost_static / max(total_batch, 1)
-            else:
-                avg_cost += step(x_all[i * bs:(i + 1) * bs], y_all[i * bs:(i + 1) * bs]) / max(total_batch, 1)
+            avg_cost += run(x_all[i * bs:(i + 1) * bs], y_all[i * bs:(i + 1) * bs]) / max(total_batch, 1)
         if verbose and epoch % int(getattr(config, "display_step", 1)) == 0:
             print(f"Epoch: {epoch + 1:04d} | cost = {float(avg_cost):.9f}")
 
