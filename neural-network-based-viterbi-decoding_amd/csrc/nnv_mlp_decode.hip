@@ -18,10 +18,14 @@
 //    the final 2-lane argmax merge.
 //  * Weights (A operands) are pre-packed on the host in fragment order and are
 //    LDS resident (one copy per CU, shared by all waves of a persistent
-//    workgroup); one ds_read_b128 feeds 4 MFMAs.  An output layer too large
-//    for the 160 KiB LDS is streamed from L2 with coalesced dwordx4 loads.
-//  * bias add + tanh (v_exp_f32 / v_rcp_f32) + running first-max argmax run on
-//    the VALU in the shadow of the MFMA pipe (several waves per SIMD).
+//    workgroup); one ds_read_b128 feeds 4 MFMAs.  Of a class layer too large
+//    for the 160 KiB LDS as many M-tiles as fit stay resident; the rest is
+//    streamed from L2 as one linear, register-double-buffered fragment stream.
+//  * bias (the accumulator's initial value) + tanh (v_exp_f32 / v_rcp_f32) +
+//    first-max argmax on clamped pre-activations run on the VALU.  On gfx950 the
+//    fp32 MFMA shares its pipe with the VALU, so every vector instruction in the
+//    tile loop is paid for: the kernel comes in three VARIANTs (general, stream,
+//    lean) so that cold options do not sit in the hot instantiation.
 //  * Received soft bits are read once, as per-lane contiguous half rows
 //    (a wave reads one contiguous 32*n_in*4-byte span), prefetched one tile
 //    ahead; decoded classes are written as one 128-byte store per tile.
@@ -48,9 +52,11 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 //   three v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate): the
 //   "3xFP16" emulation of an fp32 GEMM on the 16-bit matrix pipe.  Error per
 //   product <= ~2^-21 relative, the same order as fp32 rounding itself
-//   (measured: max |out - fp64| 1.2e-6 vs 1.0e-6 for fp32).  On gfx950 the
+//   (measured: max |out - fp64| 2.6e-6 vs 1.3e-6 for fp32).  On gfx950 the
 //   16-bit MFMA co-executes with VALU work while the fp32 MFMA does not, so
-//   this mode is bound by the tanh/argmax VALU work instead of the matrix pipe.
+//   this mode is bound by instruction issue (tanh / split / argmax), not by the
+//   matrix pipe; its activations travel as r = 1/(1+e^{2z}) with tanh's affine map
+//   folded into the packed weights (act16, pack_network_f16x3).
 
 // tanh(z) = 1 - 2 / (1 + e^{2z});  e^{2z} = 2^{z * 2 log2(e)}.
 // v_exp_f32 and v_rcp_f32 are 1-ulp hardware approximations; the absolute
