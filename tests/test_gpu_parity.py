@@ -176,7 +176,7 @@ def test_misaligned_and_strided_inputs(cuda_device):
     net.close()
 
 
-@pytest.mark.parametrize("register_host", [True, False])
+@pytest.mark.parametrize("register_host", [None, True, False])
 def test_host_array_pipeline_equals_resident_decode(cuda_device, register_host):
     """The reference's call shape (host test_set in, host predictions out): chunked,
     three-stream H2D / decode / D2H pipeline, with and without in-place page-locking."""
