@@ -685,10 +685,12 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
   plan->out_in_lds = fit == s.mt_out ? 1 : 0;
   plan->lds_bytes = static_cast<int32_t>(base_floats * 4 + fit * per_tile_bytes) + kLdsTailBytes;  // + work counter, bin counters
   plan->threads = pick_threads(s);
+  // Persistent: one workgroup per CU.  Small batches are spread over as many CUs as they have
+  // tiles (one busy wave per CU, the others find no work and leave) rather than packed 16 tiles to
+  // a CU: BASELINE configs[0] (2,000 rows) 107 -> 39 us per launch, 20,000 rows 110 -> 63 us.
   const int64_t n_tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  const int waves = plan->threads / 64;
-  int64_t blocks = (n_tiles + waves - 1) / waves;
-  if (blocks > num_cus) blocks = num_cus;  // persistent: one workgroup per CU
+  int64_t blocks = n_tiles;
+  if (blocks > num_cus) blocks = num_cus;
   if (blocks < 1) blocks = 1;
   plan->blocks = static_cast<int32_t>(blocks);
   return NNV_OK;
