@@ -19,6 +19,7 @@ through the HIP kernel.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Tuple
 
 import numpy as np
@@ -44,7 +45,7 @@ class GraphedStep:
         self._static = None
         self._cost = None
         dev = params[0].device
-        if dev.type != "cuda":
+        if dev.type != "cuda" or os.environ.get("NNV_NO_TRAIN_GRAPH"):   # the switch is for A/B tests
             return
         try:
             static = [t.clone() for t in example_inputs]

@@ -558,3 +558,29 @@ def test_concurrent_host_threads_and_streams(cuda_device):
         assert torch.equal(got[i]["counters"], want[i]["counters"])
     for net in nets:
         net.close()
+
+
+def test_graph_captured_training_step_equals_eager(cuda_device, monkeypatch):
+    """training.GraphedStep: same kernels in the same order as eager mode -> the same weights; with
+    dropout the captured step still draws a fresh mask on every replay."""
+    from nnviterbi_amd import training
+    cfg = fv.DecoderConfig(block_length=6, samples_per_class_train=10, samples_per_class_test=1,
+                           training_epochs=3, batch_size=64)
+    np.random.seed(11)
+    tr, trl, _, _, _ = fv.train_test_dataset(cfg)
+    w0, b0 = fv.initialize_weights(cfg, rng=np.random.RandomState(5))
+    got_w, got_b = training.train_network(cfg, tr, trl, w0, b0, verbose=False)
+    monkeypatch.setenv("NNV_NO_TRAIN_GRAPH", "1")
+    ref_w, ref_b = training.train_network(cfg, tr, trl, w0, b0, verbose=False)
+    monkeypatch.delenv("NNV_NO_TRAIN_GRAPH")
+    for k in got_w:
+        assert np.abs(got_w[k] - ref_w[k]).max() < 1e-5 and np.abs(got_w[k] - w0[k]).max() > 1e-4
+    for k in got_b:
+        assert np.abs(got_b[k] - ref_b[k]).max() < 1e-5
+    torch.manual_seed(0)
+    d1, _ = training.train_network(cfg, tr, trl, w0, b0, use_dropout=True, verbose=False)
+    torch.manual_seed(1)
+    d2, _ = training.train_network(cfg, tr, trl, w0, b0, use_dropout=True, verbose=False)
+    assert all(np.isfinite(v).all() for v in d1.values())
+    assert np.abs(d1["h1"] - d2["h1"]).max() > 1e-6          # different seeds -> different masks
+    assert np.abs(d1["h1"] - got_w["h1"]).max() > 1e-6       # and dropout is really applied
