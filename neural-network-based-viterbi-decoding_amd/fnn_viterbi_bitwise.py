@@ -204,21 +204,27 @@ def train_and_evaluate(config: BitwiseDecoderConfig, train_info: np.ndarray, tra
     x_all = torch.as_tensor(np.asarray(train_encoded, dtype=np.float32), device=dev)
     bit = torch.as_tensor(np.asarray(train_info)[:, config.bit_position].astype(np.int64), device=dev)
     y_all = torch.nn.functional.one_hot(bit, 2).to(torch.float32)
-    opt = torch.optim.Adam(list(W.values()) + list(B.values()), lr=config.learning_rate)
+    params = list(W.values()) + list(B.values())
+    opt = torch.optim.Adam(params, lr=config.learning_rate, capturable=(dev.type == "cuda"))
     bs = int(config.batch_size)
     total_batch = int(config.training_size / bs)
+
+    def step(xb, yb):
+        h = torch.relu(xb @ W["h1"] + B["b1"])
+        pred = torch.relu(h @ W["out"] + B["out"])
+        ce = torch.nn.functional.binary_cross_entropy_with_logits(pred, yb)
+        cost = ce + config.beta_regularization * 0.5 * ((W["h1"] ** 2).sum() + (W["h2"] ** 2).sum())
+        opt.zero_grad(set_to_none=False)
+        cost.backward()
+        opt.step()
+        return cost.detach()
+
+    from .training import GraphedStep
+    run = GraphedStep(step, params, opt, [x_all[:bs], y_all[:bs]]) if total_batch > 0 else step
     for epoch in range(int(config.training_epochs)):
         avg_cost = torch.zeros((), device=dev)
         for i in range(total_batch):
-            xb, yb = x_all[i * bs:(i + 1) * bs], y_all[i * bs:(i + 1) * bs]
-            h = torch.relu(xb @ W["h1"] + B["b1"])
-            pred = torch.relu(h @ W["out"] + B["out"])
-            ce = torch.nn.functional.binary_cross_entropy_with_logits(pred, yb)
-            cost = ce + config.beta_regularization * 0.5 * ((W["h1"] ** 2).sum() + (W["h2"] ** 2).sum())
-            opt.zero_grad(set_to_none=True)
-            cost.backward()
-            opt.step()
-            avg_cost += cost.detach() / max(total_batch, 1)
+            avg_cost += run(x_all[i * bs:(i + 1) * bs], y_all[i * bs:(i + 1) * bs]) / max(total_batch, 1)
         if epoch % config.display_step == 0:
             print(f"Epoch: {epoch + 1:04d} | cost = {float(avg_cost):.9f}")
     print("Optimization Finished!")

@@ -222,25 +222,30 @@ def _train(config: SequentialDecoderConfig, train_info, train_coded, weights, bi
     B = [torch.tensor(biases[k], dtype=torch.float32, device=dev, requires_grad=True) for k in _B_KEYS]
     stream = torch.as_tensor(np.asarray(train_coded)[0].astype(np.float32), device=dev)
     bits = torch.as_tensor(np.asarray(train_info)[0].astype(np.int64), device=dev)
-    opt = torch.optim.Adam(W + B, lr=config.learning_rate)
+    opt = torch.optim.Adam(W + B, lr=config.learning_rate, capturable=(dev.type == "cuda"))
     bs, win = int(config.batch_size), int(config.window_length)
     total_batch = int(config.total_training_instances / bs)
     windows = stream.unfold(0, win, 2)                      # window i = stream[2i : 2i + win]
+
+    def step(xb, bb):
+        yb = torch.nn.functional.one_hot(bb, 2).to(torch.float32)
+        h = xb
+        for l in range(4):
+            h = torch.tanh(h @ W[l] + B[l])
+        pred = torch.tanh(h @ W[4] + B[4])
+        ce = torch.nn.functional.binary_cross_entropy_with_logits(pred, yb)
+        cost = ce + config.beta_regularization * 0.5 * ((W[0] ** 2).sum() + (W[1] ** 2).sum())
+        opt.zero_grad(set_to_none=False)
+        cost.backward()
+        opt.step()
+        return cost.detach()
+
+    from .training import GraphedStep
+    run = GraphedStep(step, W + B, opt, [windows[:bs], bits[:bs]]) if total_batch > 0 else step
     for epoch in range(int(config.training_epochs)):
         avg_cost = torch.zeros((), device=dev)
         for i in range(total_batch):
-            xb = windows[i * bs:(i + 1) * bs]
-            yb = torch.nn.functional.one_hot(bits[i * bs:(i + 1) * bs], 2).to(torch.float32)
-            h = xb
-            for l in range(4):
-                h = torch.tanh(h @ W[l] + B[l])
-            pred = torch.tanh(h @ W[4] + B[4])
-            ce = torch.nn.functional.binary_cross_entropy_with_logits(pred, yb)
-            cost = ce + config.beta_regularization * 0.5 * ((W[0] ** 2).sum() + (W[1] ** 2).sum())
-            opt.zero_grad(set_to_none=True)
-            cost.backward()
-            opt.step()
-            avg_cost += cost.detach() / max(total_batch, 1)
+            avg_cost += run(windows[i * bs:(i + 1) * bs], bits[i * bs:(i + 1) * bs]) / max(total_batch, 1)
         if epoch % config.display_step == 0:
             print(f"Epoch: {epoch + 1:04d} | cost = {float(avg_cost):.9f}")
     return ({k: w.detach().cpu().numpy().copy() for k, w in zip(_W_KEYS, W)},
