@@ -584,3 +584,18 @@ def test_graph_captured_training_step_equals_eager(cuda_device, monkeypatch):
     assert all(np.isfinite(v).all() for v in d1.values())
     assert np.abs(d1["h1"] - d2["h1"]).max() > 1e-6          # different seeds -> different masks
     assert np.abs(d1["h1"] - got_w["h1"]).max() > 1e-6       # and dropout is really applied
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_repeated_launches_are_bitwise_identical(cuda_device, precision):
+    """On-demand tile grabbing and atomics must not leak into the results: 30 launches over the same
+    4 M rows give the same classes and the same counters every time."""
+    dims, b, n = [16, 128, 64, 32, 256], 8, 4_000_000
+    Ws, bs = _net(dims, 31)
+    net = PackedMLP(Ws, bs, precision=precision)
+    x, lab = generate_awgn_blocks("133171", b, n, 0.6, seed=12, rows_per_block=8)
+    first = net.decode(x, labels=lab, tile_bits=b)
+    for _ in range(30):
+        r = net.decode(x, labels=lab, tile_bits=b)
+        assert torch.equal(r["cls32"], first["cls32"]) and torch.equal(r["counters"], first["counters"])
+    net.close()
