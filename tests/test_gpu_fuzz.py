@@ -21,6 +21,9 @@ from oracle import rnn_oracle as R
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
+# NNV_FUZZ_SCALE=k multiplies the number of seeds per path (one-off soak runs; default 1)
+import os  # noqa: E402
+SCALE = max(1, int(os.environ.get("NNV_FUZZ_SCALE", "1")))
 
 
 def _net(dims, rng, bias_scale=0.1):
@@ -40,7 +43,7 @@ def _check_ff(cls, act, x, Ws, bs, activation="tanh"):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * SCALE))
 def test_fused_decoder_random_shapes(cuda_device, seed, precision):
     """K1: hidden widths are the first 1..3 of the reference's (128, 64, 32), everything else random."""
     rng = np.random.RandomState(1000 + seed)
@@ -64,7 +67,7 @@ def test_fused_decoder_random_shapes(cuda_device, seed, precision):
     net.close()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 * SCALE))
 def test_wide_decoder_random_shapes(cuda_device, seed):
     """K4: 2..6 layers of arbitrary widths, matrix rows or a strided stream, tanh or ReLU."""
     rng = np.random.RandomState(2000 + seed)
@@ -89,7 +92,7 @@ def test_wide_decoder_random_shapes(cuda_device, seed):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 * SCALE))
 def test_recurrent_decoder_random_shapes(cuda_device, seed, precision):
     """K5: hidden 1..22, independent encoder/decoder lengths (0 allowed for the encoder), ragged batch."""
     rng = np.random.RandomState(3000 + seed)
