@@ -131,10 +131,16 @@ bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vect
   return in_range;
 }
 
-// Fragment order: see nnv_internal.h.
+// Fragment order: see nnv_internal.h.  The hidden layers are packed scaled by 2 log2(e) (their
+// accumulators then hold the argument of the exp2 in tanh z = 1 - 2/(1 + 2^{2 log2(e) z}), act16 in
+// nnv_mlp_decode.hip); the class layer is packed as it is (its raw pre-activations feed the argmax).
 void pack_network(const nnv_mlp_desc *net, const PackedShape &s, std::vector<float> *out) {
   out->assign(static_cast<size_t>(s.hid_floats + s.out_floats + s.bias_floats), 0.f);
   float *w = out->data();
+  constexpr double kTwoLog2e = 2.8853900817779268;
+  auto scaled = [&](int l, float v) {
+    return l == net->depth - 1 ? v : static_cast<float>(kTwoLog2e * static_cast<double>(v));
+  };
   // layer 1
   {
     const int M = net->dims[1];
@@ -147,7 +153,7 @@ void pack_network(const nnv_mlp_desc *net, const PackedShape &s, std::vector<flo
             const int k = (lane >> 5) * s.bp + step;
             const int i = 32 * mt + (lane & 31);
             const bool ok = step < s.bp && k < s.n_in && i < M;
-            *w++ = ok ? W[static_cast<size_t>(k) * M + i] : 0.f;
+            *w++ = ok ? scaled(0, W[static_cast<size_t>(k) * M + i]) : 0.f;
           }
   }
   // layers 2..depth (the last one is the output layer; same fragment rule)
@@ -164,14 +170,14 @@ void pack_network(const nnv_mlp_desc *net, const PackedShape &s, std::vector<flo
               const int k = 32 * kt + e + 8 * q + 4 * (lane >> 5);
               const int i = 32 * mt + (lane & 31);
               const bool ok = k < K && i < M;
-              *w++ = ok ? W[static_cast<size_t>(k) * M + i] : 0.f;
+              *w++ = ok ? scaled(l, W[static_cast<size_t>(k) * M + i]) : 0.f;
             }
   }
   // biases, each layer padded to a multiple of 32
   for (int l = 0; l < net->depth; ++l) {
     const int M = net->dims[l + 1];
     const int MT = (l == net->depth - 1) ? s.mt_out : s.mt[l];
-    for (int i = 0; i < 32 * MT; ++i) *w++ = i < M ? net->b_host[l][i] : 0.f;
+    for (int i = 0; i < 32 * MT; ++i) *w++ = i < M ? scaled(l, net->b_host[l][i]) : 0.f;
   }
 }
 

@@ -171,19 +171,21 @@ __device__ __forceinline__ f32x16 init_acc(const float *bias_tile, int half) {
   return acc;
 }
 
-// Hidden-layer activation as the NEXT layer consumes it.
-//  fp32 : a = tanh(z), the reference's op as it stands.
-//  f16x3: r = 1 / (1 + 2^zeta) with zeta = 2 log2(e) z, so tanh(z) = 1 - 2r.  The scale is
-//         folded into this layer's packed weights and bias, the affine map 1 - 2r into the
-//         next layer's (W' = -2W, b' = b + sum_k W_k; pack_network_f16x3 in nnv_capi.hip):
-//         3 VALU instructions per activation instead of 5 in the mode that is VALU-bound.
-//         Limits stay exact: zeta -> +inf gives r = 0 (tanh 1), -inf gives r = 1 (tanh -1).
+// Hidden-layer activation as the NEXT layer consumes it.  In BOTH modes the hidden layers' packed
+// weights and biases carry the factor 2 log2(e) (prepack, computed in double), so the accumulator
+// holds zeta = 2 log2(e) z and tanh(z) = 1 - 2 / (1 + 2^zeta) needs no multiply in the tile loop.
+//  fp32 : a = tanh(z) = fma(-2, rcp(1 + exp2(zeta)), 1).
+//  f16x3: r = 1 / (1 + 2^zeta), i.e. tanh(z) = 1 - 2r with the affine map folded into the next
+//         layer's packed weights as well (W' = -2W, b' = b + sum_k W_k; pack_network_f16x3 in
+//         nnv_capi.hip): 3 VALU instructions per activation in the mode that is issue-bound.
+//  Limits stay exact: zeta -> +inf gives rcp(inf) = 0 (tanh 1), -inf gives rcp(1) = 1 (tanh -1).
 template <int PREC>
 __device__ __forceinline__ void act16(f32x16 &acc) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    if constexpr (PREC == kPrecF32) acc[r] = tanh_f32(acc[r]);
-    else acc[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r]));
+    const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r]));
+    if constexpr (PREC == kPrecF32) acc[r] = __builtin_fmaf(-2.0f, rr, 1.0f);
+    else acc[r] = rr;
   }
 }
 
