@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void seq2seq_kernel(const Seq2SeqParams p) {
   const int64_t row_c = live ? row : p.batch - 1;
 
   CellWeights<S, PREC> W;
-  float c[S], h[S];
+  float c[S], h[S];   // c: the cell state times 2 log2(e) (see step), h: the output m
 #pragma unroll
   for (int k = 0; k < S; ++k) c[k] = h[k] = 0.f;
 
@@ -206,9 +206,11 @@ __global__ __launch_bounds__(256) void seq2seq_kernel(const Seq2SeqParams p) {
       const float sf = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zf));
       const float so = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zo));
       const float rj = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zj));
-      const float tj = __builtin_fmaf(-2.0f, rj, 1.0f);                      // tanh(j)
+      // the cell state is carried as ct = 2 log2(e) c, the argument tanh(c)'s exp2 wants:
+      // ct' = sig(f) ct + sig(i) (2 log2(e) tanh(j)), tanh(j) = 1 - 2 rj
+      const float tj = __builtin_fmaf(-2.0f * kTwoLog2e, rj, kTwoLog2e);
       const float cn = __builtin_fmaf(si, tj, sf * c[k]);
-      const float rc = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cn * kTwoLog2e));
+      const float rc = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cn));
       c[k] = cn;
       h[k] = so * __builtin_fmaf(-2.0f, rc, 1.0f);                           // sig(o) tanh(c)
     }
