@@ -25,6 +25,10 @@ The headline line is the exact-fp32 path (dtype "f32").  The same workload is
 then timed once more in the f16x3 precision mode and reported under
 "fast_mode" (never as `value`).
 
+`ber` / `fer` are the reference's metrics per row of its input matrix (one b = 8 tile:
+src/fnn_viterbi.py:639-671); `block_error_rate` counts a 64-bit block as wrong if any of its 8
+tiles is.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -162,6 +166,11 @@ def main():
     total = counters.clone()
     nd.all_reduce_counters(total)          # the path's one collective (RCCL)
     ber, fer = nd.rates(total.cpu().numpy())
+    # block error rate (a block of L = 64 bits is wrong if any of its 8 tiles is), outside the timed region
+    blk = torch.stack([(cls != labels).view(n_blocks, ROWS_PER_BLOCK).any(dim=1).sum(),
+                       torch.tensor(n_blocks, device=dev)]).to(torch.int64)
+    nd.all_reduce_counters(blk)
+    bler = float(blk[0].item()) / float(blk[1].item())
 
     # ---- the same workload in the other precision mode (reported beside) ----
     other = "f16x3" if args.precision == "f32" else "f32"
@@ -209,7 +218,7 @@ def main():
                 "net": dims, "weights": weights_desc,
                 "parallelism": f"block-shard x{world}, counters all-reduce only",
             },
-            "ber": ber, "fer": fer,
+            "ber": ber, "fer": fer, "block_error_rate": bler,
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision],
                 "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS[args.precision], "traffic": traffic,
