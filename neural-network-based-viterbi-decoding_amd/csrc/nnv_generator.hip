@@ -53,6 +53,10 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &n0, fl
   n1 = rad * s;
 }
 
+// TB > 0: tile_bits known at compile time (7, 8, 10: the reference default and BASELINE's tilings):
+// the row is built in registers and leaves as 16-byte stores (4 per 64-byte row instead of 16
+// four-byte ones).  TB = 0: any tile_bits, scalar stores.  Same draws, same arithmetic, same data.
+template <int TB>
 __global__ __launch_bounds__(256) void awgn_generate_kernel(const GenParams p) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -61,14 +65,15 @@ __global__ __launch_bounds__(256) void awgn_generate_kernel(const GenParams p) {
     const uint32_t r_lo = static_cast<uint32_t>(r), r_hi = static_cast<uint32_t>(r >> 32);
     uint32_t rnd[4];
     philox4x32_10(r_lo, r_hi, 0u, 0u, p.seed_lo, p.seed_hi, rnd);
-    const int b = p.tile_bits;
+    const int b = TB > 0 ? TB : p.tile_bits;
     const uint32_t cls = rnd[0] & ((1u << b) - 1u);  // MSB-first value of the info bits
     // u(t) = info bit t (t = 0 is the first bit in time = the MSB of cls)
     auto u = [&](int t) -> uint32_t { return t < 0 ? 0u : (cls >> (b - 1 - t)) & 1u; };
     const int64_t blk = static_cast<int64_t>(r / static_cast<uint64_t>(p.rows_per_block));
     const float sigma = p.sigma[blk % p.n_sigma];
     float *px = p.x + i * (2 * b);
-    for (int t0 = 0; t0 < b; t0 += 2) {  // 2 info bits -> 4 coded symbols -> 1 Philox draw
+    float row[TB > 0 ? 2 * TB + 2 : 4];   // TB > 0: the whole row (+2: odd TB draws a spare pair)
+    auto two_bits = [&](int t0) {  // 2 info bits -> 4 coded symbols -> 1 Philox draw
       uint32_t g[4];
       philox4x32_10(r_lo, r_hi, static_cast<uint32_t>(t0 >> 1), 1u, p.seed_lo, p.seed_hi, g);
       float nz[4];
@@ -89,8 +94,38 @@ __global__ __launch_bounds__(256) void awgn_generate_kernel(const GenParams p) {
           e0 = u(t) ^ u(t - 2);
           e1 = (t == 0) ? (u(0) ^ u(1)) : (u(t) ^ u(t - 1) ^ u(t - 2));
         }
-        px[2 * t] = (e0 ? 1.0f : -1.0f) + sigma * nz[2 * d];
-        px[2 * t + 1] = (e1 ? 1.0f : -1.0f) + sigma * nz[2 * d + 1];
+        const float v0 = (e0 ? 1.0f : -1.0f) + sigma * nz[2 * d];
+        const float v1 = (e1 ? 1.0f : -1.0f) + sigma * nz[2 * d + 1];
+        if constexpr (TB > 0) {
+          row[2 * t] = v0;
+          row[2 * t + 1] = v1;
+        } else {
+          px[2 * t] = v0;
+          px[2 * t + 1] = v1;
+        }
+      }
+    };
+    if constexpr (TB > 0) {
+#pragma unroll
+      for (int t0 = 0; t0 < TB; t0 += 2) two_bits(t0);
+    } else {
+      for (int t0 = 0; t0 < b; t0 += 2) two_bits(t0);
+    }
+    if constexpr (TB > 0) {
+      using f32x4 = __attribute__((ext_vector_type(4))) float;
+      using f32x2 = __attribute__((ext_vector_type(2))) float;
+      if constexpr ((2 * TB) % 4 == 0) {   // rows are 16-byte aligned: x comes from hipMalloc, 2 TB * 4 B % 16 == 0
+#pragma unroll
+        for (int q = 0; q < 2 * TB / 4; ++q) {
+          const f32x4 v = {row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]};
+          *reinterpret_cast<f32x4 *>(px + 4 * q) = v;
+        }
+      } else {                             // 8-byte aligned rows (TB odd)
+#pragma unroll
+        for (int q = 0; q < TB; ++q) {
+          const f32x2 v = {row[2 * q], row[2 * q + 1]};
+          *reinterpret_cast<f32x2 *>(px + 2 * q) = v;
+        }
       }
     }
     if (p.labels) p.labels[i] = static_cast<int32_t>(cls);
@@ -114,7 +149,12 @@ nnv_status generate_launch(int32_t code, int32_t tile_bits, int64_t n_rows, int6
   p.labels = labels;
   int64_t blocks = (n_rows + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(awgn_generate_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  const bool aligned = reinterpret_cast<uintptr_t>(x) % 16 == 0;
+  if (tile_bits == 8 && aligned) hipLaunchKernelGGL(awgn_generate_kernel<8>, grid, block, 0, stream, p);
+  else if (tile_bits == 10 && aligned) hipLaunchKernelGGL(awgn_generate_kernel<10>, grid, block, 0, stream, p);
+  else if (tile_bits == 7 && aligned) hipLaunchKernelGGL(awgn_generate_kernel<7>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(awgn_generate_kernel<0>, grid, block, 0, stream, p);
   return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 
