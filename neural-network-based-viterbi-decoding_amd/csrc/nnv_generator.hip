@@ -42,15 +42,17 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Box-Muller on 24-bit uniforms: u1 in (0,1], u2 in [0,1).
+// Box-Muller on 24-bit uniforms: u1 in (0,1], u2 in [0,1), on the hardware transcendentals:
+// v_log_f32 (log2), v_sqrt_f32, and v_sin_f32 / v_cos_f32, which take their argument in
+// REVOLUTIONS, i.e. sin(2 pi u2) is v_sin_f32(u2) with no range reduction.  Contract (the numpy
+// model in oracle/awgn_model.py evaluates the same formulas in float64): x within 1e-5.
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &n0, float &n1) {
   const float u1 = (static_cast<float>(a >> 8) + 1.0f) * 5.9604644775390625e-08f;
   const float u2 = static_cast<float>(b >> 8) * 5.9604644775390625e-08f;
-  const float rad = sqrtf(-2.0f * logf(u1));
-  float s, c;
-  sincospif(2.0f * u2, &s, &c);
-  n0 = rad * c;
-  n1 = rad * s;
+  // -2 ln(u1) = -2 ln(2) log2(u1)
+  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+  n0 = rad * __builtin_amdgcn_cosf(u2);
+  n1 = rad * __builtin_amdgcn_sinf(u2);
 }
 
 // TB > 0: tile_bits known at compile time (7, 8, 10: the reference default and BASELINE's tilings):
