@@ -173,7 +173,7 @@ def _time_major(feed: np.ndarray) -> np.ndarray:
 
 
 def run_seq2seq(model: Dict, feeds: Dict, n_bits: Optional[int] = None, info_bits01=None,
-                device=None) -> Dict:
+                device=None, precision: str = "f32") -> Dict:
     """``sess.run(model['decoder_prediction'], feed_dict)`` (src/rnn_viterbi.py:471-474) on the
     MI355X.  Returns ``decoder_logits`` float32 [T_dec, B], ``decoder_prediction`` int64 [T_dec, B]
     (argmax over the size-1 vocabulary axis: zeros), and, as an extension, ``hard_bits`` uint8
@@ -184,7 +184,8 @@ def run_seq2seq(model: Dict, feeds: Dict, n_bits: Optional[int] = None, info_bit
     enc = _time_major(feeds["encoder_inputs"])
     dec = _time_major(feeds["decoder_inputs"])
     n_bits = cfg.block_length if n_bits is None else int(n_bits)
-    net = Seq2SeqLSTM(model["params"], forget_bias=model.get("forget_bias", 1.0), device=device)
+    net = Seq2SeqLSTM(model["params"], forget_bias=model.get("forget_bias", 1.0), device=device,
+                      precision=precision)     # "f16x3": hi/lo f16 operands, ~2x, same 5e-5 tolerance
     try:
         dev = net.device
         info = None

@@ -114,6 +114,8 @@ def test_reference_shaped_run_and_literal_ber(cuda_device, capsys):
     assert np.array_equal(r["decoder_prediction"], pred)
     assert np.array_equal(r["hard_bits"], R.hard_bits(r["decoder_logits"], 8))
     assert np.array_equal(r["counters"], R.error_counters(r["hard_bits"], test_info == 1))
+    fast = rv.run_seq2seq(model, feeds, precision="f16x3")
+    assert np.abs(fast["decoder_logits"] - want).max() < TOL
 
 
 def test_errors_and_empty_batches(cuda_device):
