@@ -11,6 +11,7 @@ Replaces the reference's ``Session.run`` of
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -24,6 +25,26 @@ def _as_host_f32(a) -> np.ndarray:
     if isinstance(a, torch.Tensor):
         a = a.detach().to("cpu").numpy()
     return np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+
+
+_DEFAULT_PRECISION = [os.environ.get("NNV_PRECISION", "f32")]
+
+
+def set_default_precision(precision: str) -> None:
+    """Arithmetic of every decoder object built without an explicit ``precision`` (so also of the
+    reference-shaped modules, which build them internally): "f32" (exact fp32 MFMA chains, the
+    default and the parity reference) or "f16x3" (hi/lo f16 split operands, ~2-3x faster, same
+    stated tolerances).  The environment variable ``NNV_PRECISION`` sets the initial value."""
+    if precision not in _cabi.NNV_PRECISION:
+        raise ValueError(f"precision must be one of {sorted(_cabi.NNV_PRECISION)}")
+    _DEFAULT_PRECISION[0] = precision
+
+
+def _resolve_precision(precision: Optional[str]) -> str:
+    p = _DEFAULT_PRECISION[0] if precision is None else precision
+    if p not in _cabi.NNV_PRECISION:
+        raise ValueError(f"precision must be one of {sorted(_cabi.NNV_PRECISION)}")
+    return p
 
 
 def _require_cuda():
@@ -49,13 +70,12 @@ class PackedMLP:
     2..4 dense layers, the last one being the class layer.
     """
 
-    def __init__(self, weights: Sequence, biases: Sequence, device=None, precision: str = "f32"):
+    def __init__(self, weights: Sequence, biases: Sequence, device=None, precision: Optional[str] = None):
         """``precision``: "f32" (exact fp32 MFMA chain, the default and the parity
         reference) or "f16x3" (hi/lo f16 split operands on the 16-bit matrix pipe,
         fp32 accumulate: ~2^-21 relative error per product, ~3x the throughput)."""
         _require_cuda()
-        if precision not in _cabi.NNV_PRECISION:
-            raise ValueError(f"precision must be one of {sorted(_cabi.NNV_PRECISION)}")
+        precision = _resolve_precision(precision)
         self.precision = precision
         self._lib = _cabi.load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()
@@ -365,7 +385,7 @@ class WideMLP:
     materialising the [N, window] matrix the reference builds in Python (:507-519)."""
 
     def __init__(self, weights: Sequence, biases: Sequence, device=None, chunk_rows: int = 1 << 18,
-                 activation: str = "tanh", precision: str = "f32"):
+                 activation: str = "tanh", precision: Optional[str] = None):
         """``activation``: "tanh" (sliding-window decoder) or "relu" (bit-wise decoder,
         src/fnn_viterbi_bitwise.py:388-397), applied after every layer, the class layer included.
         ``precision``: "f32" (exact fp32 MFMA) or "f16x3" (hi/lo f16 operand planes, fp32
@@ -373,8 +393,10 @@ class WideMLP:
         _require_cuda()
         if activation not in _cabi.NNV_ACTIVATION:
             raise ValueError("activation must be 'tanh' or 'relu'")
-        if precision not in _cabi.NNV_PRECISION:
-            raise ValueError(f"precision must be one of {sorted(_cabi.NNV_PRECISION)}")
+        explicit = precision is not None
+        precision = _resolve_precision(precision)
+        if precision == "f16x3" and not explicit and np.asarray(biases[-1]).reshape(-1).shape[0] > 32:
+            precision = "f32"     # the split path ends in the narrow head kernel: a DEFAULT must not break wide heads
         self.precision = precision
         self._lib = _cabi.load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()
@@ -461,10 +483,9 @@ class Seq2SeqLSTM:
     CUDA tensors, the layout of the reference's placeholders (:263-279)."""
 
     def __init__(self, params: Dict[str, np.ndarray], forget_bias: float = 1.0, device=None,
-                 precision: str = "f32"):
+                 precision: Optional[str] = None):
         _require_cuda()
-        if precision not in _cabi.NNV_PRECISION:
-            raise ValueError(f"precision must be one of {sorted(_cabi.NNV_PRECISION)}")
+        precision = _resolve_precision(precision)
         self.precision = precision
         self._lib = _cabi.load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()

@@ -173,7 +173,7 @@ def _time_major(feed: np.ndarray) -> np.ndarray:
 
 
 def run_seq2seq(model: Dict, feeds: Dict, n_bits: Optional[int] = None, info_bits01=None,
-                device=None, precision: str = "f32") -> Dict:
+                device=None, precision: Optional[str] = None) -> Dict:
     """``sess.run(model['decoder_prediction'], feed_dict)`` (src/rnn_viterbi.py:471-474) on the
     MI355X.  Returns ``decoder_logits`` float32 [T_dec, B], ``decoder_prediction`` int64 [T_dec, B]
     (argmax over the size-1 vocabulary axis: zeros), and, as an extension, ``hard_bits`` uint8

@@ -199,3 +199,26 @@ def test_relu_network_in_f16x3_precision(cuda_device):
     bad = r["cls32"].cpu().numpy() != c64
     assert not bad.any() or O.top2_margin(o64)[bad].max() < 1e-4
     net.close()
+
+
+def test_default_precision_switch_reaches_the_reference_shaped_modules(cuda_device):
+    """decoder.set_default_precision / NNV_PRECISION: objects built without an explicit precision
+    (the mirrored modules build theirs internally) follow it; results stay inside the tolerances."""
+    from nnviterbi_amd import decoder, fnn_viterbi as fv
+    cfg = fv.DecoderConfig(block_length=7)
+    w, b = fv.initialize_weights(cfg, rng=np.random.RandomState(6))
+    x = (np.random.RandomState(7).randn(4000, 14) * 1.1).astype(np.float32)
+    exact, _ = fv.predict(x, w, b)
+    decoder.set_default_precision("f16x3")
+    try:
+        assert decoder.PackedMLP(*fv.weights_as_lists(w, b)).precision == "f16x3"
+        fast, _ = fv.predict(x, w, b)
+        wide = decoder.WideMLP(*_net([16, 256, 128], 0))          # > 32 classes: the default falls back to f32
+        assert wide.precision == "f32"
+        wide.close()
+    finally:
+        decoder.set_default_precision("f32")
+    assert (fast != exact).sum() <= 2
+    assert decoder.PackedMLP(*fv.weights_as_lists(w, b)).precision == "f32"
+    with pytest.raises(ValueError):
+        decoder.set_default_precision("bf16")
