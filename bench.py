@@ -3,8 +3,12 @@
 Viterbi decode path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-            --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+    (N > 1: either under torchrun, one rank per GPU --
+            python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+            --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+        or as the bare command above: with no torchrun environment the parent starts exactly that
+        launcher as a CHILD process before anything here touches the GPU, waits, and exits with
+        its return code.)
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on;
 SURVEY.md section 8d "Config 3"): (133,171) K=7 code, block_len L=64 decoded as
@@ -34,6 +38,8 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -65,11 +71,15 @@ def algorithmic_work(dims):
     return flop, byts
 
 
-def cpu_baseline(x_dev, labels_dev, Ws, bs, hip_cls, budget_s=12.0):
-    """The oracle's C restatement (oracle/fnn_oracle.c, OpenMP over rows, all
-    host threads) timed on a bounded sample of the same rows; also the parity
-    check of the HIP classes on that sample.  cpu_baseline leg only."""
+def cpu_baseline(x_dev, labels_dev, Ws, bs, hip_cls, budget_s=12.0, torch_budget_s=8.0):
+    """cpu_baseline leg only.  Two CPU implementations timed on a bounded sample of the same rows,
+    on the box's host threads; both double as the parity check of the HIP classes on that sample.
+      * headline `value`: the oracle's C restatement (oracle/fnn_oracle.c, OpenMP over rows);
+      * `torch_cpu`: matmul -> add -> tanh x4 -> argmax on PyTorch's CPU kernels in ONE call over the
+        sample (mirrors the reference's single full-set Session.run,
+        src/fnn_viterbi.py:610) -- the only independent fp32 implementation importable here."""
     from oracle import fnn_oracle as O
+    from oracle import torch_cpu as T
     threads = O.c_max_threads()
     probe = 200_000
     xs = x_dev[:probe].cpu().numpy()
@@ -86,15 +96,59 @@ def cpu_baseline(x_dev, labels_dev, Ws, bs, hip_cls, budget_s=12.0):
     hip = hip_cls[:n].cpu().numpy()
     mism = int((hip != ref["cls"]).sum())
     hip_cnt = O.error_counters(hip, ls, TILE_BITS)
+
+    # torch-CPU: probe, then one call over a sample sized to the budget (>= 1 M rows when it fits)
+    t0 = time.perf_counter()
+    T.decode(xs[:probe], Ws, bs)
+    trate = probe / (time.perf_counter() - t0)
+    nt = int(min(n, max(1_000_000, trate * torch_budget_s)))
+    nt -= nt % ROWS_PER_BLOCK
+    t0 = time.perf_counter()
+    tcls, _ = T.decode(xs[:nt], Ws, bs)
+    tdt = time.perf_counter() - t0
+    tcnt = O.error_counters(tcls, ls[:nt], TILE_BITS)
     return {
         "value": (n / ROWS_PER_BLOCK) / dt, "unit": "blocks/s", "cores": threads, "kind": "port",
         "sample": f"first {n // ROWS_PER_BLOCK} blocks ({n} rows) of the same workload, "
                   f"oracle/fnn_oracle.c fp32 fmaf chain + libm tanhf, OpenMP {threads} threads "
                   f"(the reference's TensorFlow-CPU path is not installable offline)",
+        "torch_cpu": {
+            "value": (nt / ROWS_PER_BLOCK) / tdt, "unit": "blocks/s", "cores": T.n_threads(),
+            "sample": f"first {nt // ROWS_PER_BLOCK} blocks ({nt} rows), one call: torch.matmul -> add -> "
+                      f"tanh x4 -> argmax on PyTorch CPU kernels (oracle/torch_cpu.py), fp32",
+        },
     }, {
         "rows": n, "class_mismatches": mism,
         "ber_hip": hip_cnt[0] / hip_cnt[2], "ber_cpu": int(ref["counters"][0]) / int(ref["counters"][2]),
+        "torch_cpu_rows": nt,
+        "class_mismatches_hip_vs_torch_cpu": int((hip[:nt] != tcls).sum()),
+        "class_mismatches_c_vs_torch_cpu": int((ref["cls"][:nt] != tcls).sum()),
+        "ber_torch_cpu": int(tcnt[0]) / int(tcnt[2]),
     }
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks: int) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start the ranks ourselves.
+
+    Runs `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a child
+    process and returns its exit code.  Called before this process has made any HIP /
+    torch.cuda call (a process that has initialised the GPU must never exec or fork GPU work), and
+    it is a plain child, not an exec."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this host driver
+    env["NNV_BENCH_LAUNCHED"] = "1"
+    print(f"bench.py: no torchrun environment, launching {n_ranks} ranks: {' '.join(cmd)}",
+          file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -109,18 +163,36 @@ def main():
                          "f16x3: hi/lo f16 split operands, fp32 accumulate")
     args = ap.parse_args()
 
-    rank, local_rank, world = nd.init_from_env()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))       # nothing above touched the GPU
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
-                  f"torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py needs an MI355X (no CPU fallback for the decode path)", file=sys.stderr)
+    backend = os.environ.get("NNV_DIST_BACKEND") or "nccl"   # "nccl" IS RCCL on ROCm
+    n_dev = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    if n_dev == 0 or not torch.cuda.is_available():
+        print(f"bench.py rank {rank}/{world}: needs an MI355X (no CPU fallback for the decode path)",
+              file=sys.stderr, flush=True)
         sys.exit(3)
-    dev_index = local_rank % torch.cuda.device_count()   # == local_rank except in a 1-GPU rehearsal
+    if backend == "nccl" and world > n_dev:
+        print(f"bench.py rank {rank}/{world}: {world} ranks but {n_dev} GPUs visible (RCCL needs one GPU "
+              f"per rank; NNV_DIST_BACKEND=gloo rehearses the N-rank path on fewer)", file=sys.stderr, flush=True)
+        sys.exit(3)
+    # ONE device index per rank, used for set_device, the process group and every allocation
+    dev_index = local_rank % n_dev               # == local_rank except in a gloo rehearsal on fewer GPUs
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    nd.init_from_env(backend=backend if world > 1 else None, device_index=dev_index)
+    # proof that the collective spans N ranks: SUM of ones over the data path's own backend
+    ones = torch.ones(1, dtype=torch.int64, device=dev)
+    nd.all_reduce_counters(ones)
+    ranks_seen = int(ones.item())
+    devices = nd.gather_ints(dev_index, device=dev)
 
     # ---- network: seeded initialisation of the reference architecture ----
     cfg = fv.DecoderConfig(block_length=TILE_BITS, snr_db=SNR_DB)
@@ -207,7 +279,9 @@ def main():
             "metric": "decoded blocks/sec, (133,171) block_len=64 @ SNR 2 dB",
             "value": world * n_blocks * args.steps / elapsed,
             "unit": "blocks/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_seen": ranks_seen, "rank_devices": devices,
+            "dist_backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else None),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",

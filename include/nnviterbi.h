@@ -17,7 +17,12 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *     every launch is stream-ordered and returns without synchronising;
  *   - every function returns an nnv_status (0 = NNV_OK); no exceptions, no
- *     global mutable state besides a per-process kernel-attribute cache;
+ *     global mutable state besides a kernel-attribute cache kept per (device,
+ *     kernel), so one process may drive several GPUs;
+ *   - a handle belongs to the HIP device that was current when it was packed:
+ *     every launch entry compares that device with the calling thread's current
+ *     device FIRST and returns NNV_ERR_INVALID_ARGUMENT on a mismatch (nothing is
+ *     launched; foreign-device pointers would fault, not fail);
  *   - there is NO CPU fallback: without a HIP device every compute entry
  *     point returns NNV_ERR_NO_DEVICE / the HIP error.
  */
@@ -81,6 +86,11 @@ const char *nnv_status_string(int32_t status);
 
 /* Number of visible gfx950 devices (0 if none); never fails. */
 int32_t nnv_device_count(void);
+
+/* The device rule every launch entry applies to its handle: NNV_OK iff `device`
+ * is the calling thread's current HIP device, NNV_ERR_INVALID_ARGUMENT if another
+ * device is current, NNV_ERR_NO_DEVICE without a HIP device. */
+int32_t nnv_check_device(int32_t device);
 
 /*
  * Replaces: building the TF variables + graph for multilayer_perceptron

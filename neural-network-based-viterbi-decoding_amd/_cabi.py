@@ -23,7 +23,7 @@ NNV_CODE_133171 = 1
 NNV_PRECISION = {"f32": 0, "f16x3": 1}
 
 EXPORTED_SYMBOLS = (
-    "nnv_abi_version", "nnv_status_string", "nnv_device_count",
+    "nnv_abi_version", "nnv_status_string", "nnv_device_count", "nnv_check_device",
     "nnv_mlp_prepack", "nnv_mlp_prepack_ex", "nnv_mlp_free", "nnv_mlp_decode_f32", "nnv_mlp_decode_binned_f32",
     "nnv_mlp_forward_f32", "nnv_awgn_generate_f32",
     "nnv_mlp_decode_f32_timed", "nnv_mlp_launch_info",
@@ -109,6 +109,8 @@ def load_library() -> ctypes.CDLL:
     lib.nnv_status_string.argtypes = [c.c_int32]
     lib.nnv_device_count.restype = c.c_int32
     lib.nnv_device_count.argtypes = []
+    lib.nnv_check_device.restype = c.c_int32
+    lib.nnv_check_device.argtypes = [c.c_int32]
     lib.nnv_mlp_prepack.restype = c.c_int32
     lib.nnv_mlp_prepack.argtypes = [c.POINTER(MlpDesc), c.POINTER(c.c_void_p)]
     lib.nnv_mlp_prepack_ex.restype = c.c_int32

@@ -133,13 +133,16 @@ bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vect
 
 // Fragment order: see nnv_internal.h.  The hidden layers are packed scaled by 2 log2(e) (their
 // accumulators then hold the argument of the exp2 in tanh z = 1 - 2/(1 + 2^{2 log2(e) z}), act16 in
-// nnv_mlp_decode.hip); the class layer is packed as it is (its raw pre-activations feed the argmax).
+// nnv_mlp_decode.hip); the class layer keeps its scale (its raw pre-activations feed the argmax).
+// With kFoldF32 the kernel hands r = 1/(1 + 2^zeta) from layer to layer instead of tanh z = 1 - 2r,
+// so layers >= 2 are packed as W' = -2 W (exact) and b' = b + sum_k W_k (double, one rounding).
 void pack_network(const nnv_mlp_desc *net, const PackedShape &s, std::vector<float> *out) {
   out->assign(static_cast<size_t>(s.hid_floats + s.out_floats + s.bias_floats), 0.f);
   float *w = out->data();
   constexpr double kTwoLog2e = 2.8853900817779268;
-  auto scaled = [&](int l, float v) {
-    return l == net->depth - 1 ? v : static_cast<float>(kTwoLog2e * static_cast<double>(v));
+  auto scaled = [&](int l, double v) {
+    const double f = (nnv::kFoldF32 && l >= 1) ? -2.0 : 1.0;
+    return static_cast<float>((l == net->depth - 1 ? f : f * kTwoLog2e) * v);
   };
   // layer 1
   {
@@ -175,16 +178,28 @@ void pack_network(const nnv_mlp_desc *net, const PackedShape &s, std::vector<flo
   }
   // biases, each layer padded to a multiple of 32
   for (int l = 0; l < net->depth; ++l) {
-    const int M = net->dims[l + 1];
+    const int K = net->dims[l], M = net->dims[l + 1];
     const int MT = (l == net->depth - 1) ? s.mt_out : s.mt[l];
-    for (int i = 0; i < 32 * MT; ++i) *w++ = i < M ? scaled(l, net->b_host[l][i]) : 0.f;
+    const double sc = l == net->depth - 1 ? 1.0 : kTwoLog2e;
+    for (int i = 0; i < 32 * MT; ++i) {
+      double b = 0.0;
+      if (i < M) {
+        b = net->b_host[l][i];
+        if (nnv::kFoldF32 && l >= 1)
+          for (int k = 0; k < K; ++k) b += net->W_host[l][static_cast<size_t>(k) * M + i];
+        b *= sc;
+      }
+      *w++ = static_cast<float>(b);
+    }
   }
 }
 
 nnv_status make_params(const nnv_mlp_handle *h, const float *x_dev, int64_t n_rows,
                        DecodeParams *p, LaunchPlan *plan) {
   const PackedShape &s = h->shape;
-  const nnv_status st = nnv::decode_plan(s, n_rows, h->num_cus, h->lds_limit, plan);
+  const nnv_status dv = nnv::check_current_device(h->device);
+  if (dv != NNV_OK) return dv;
+  const nnv_status st = nnv::decode_plan(s, n_rows, h->num_cus, h->lds_limit, h->threads, plan);
   if (st != NNV_OK) return st;
   memset(p, 0, sizeof(*p));
   p->x = x_dev;
@@ -207,14 +222,24 @@ nnv_status make_params(const nnv_mlp_handle *h, const float *x_dev, int64_t n_ro
 
 }  // namespace
 
+namespace nnv {
+nnv_status check_current_device(int device) {
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) return NNV_ERR_NO_DEVICE;
+  return cur == device ? NNV_OK : NNV_ERR_INVALID_ARGUMENT;
+}
+}  // namespace nnv
+
 extern "C" {
 
 int32_t nnv_abi_version(void) { return NNV_ABI_VERSION; }
 
+int32_t nnv_check_device(int32_t device) { return nnv::check_current_device(device); }
+
 const char *nnv_status_string(int32_t status) {
   switch (status) {
     case NNV_OK: return "ok";
-    case NNV_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case NNV_ERR_INVALID_ARGUMENT: return "invalid argument (NULL / bad size / handle packed for another device)";
     case NNV_ERR_UNSUPPORTED_SHAPE: return "unsupported network shape (no kernel instantiation)";
     case NNV_ERR_NO_DEVICE: return "no gfx950 HIP device";
     case NNV_ERR_HIP: return "HIP runtime error";
@@ -275,7 +300,9 @@ int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision, nnv_mlp_h
     delete h;
     return NNV_ERR_HIP;
   }
-  const nnv_status prep = nnv::decode_prepare(s, h->num_cus, h->lds_limit);
+  h->threads = nnv::decode_pick_threads(s);
+  h->vgprs = nnv::decode_kernel_vgprs(s, h->threads);
+  const nnv_status prep = nnv::decode_prepare(s, h->num_cus, h->lds_limit, h->threads, dev);
   if (prep != NNV_OK) {
     (void)hipFree(h->wpack_dev);
     delete h;
@@ -314,7 +341,7 @@ int32_t nnv_mlp_decode_f32(const nnv_mlp_handle *h, const float *x_dev, int64_t 
   p.cls64 = cls64_dev;
   p.bits = bits_dev;
   p.counters = reinterpret_cast<unsigned long long *>(counters_dev);
-  return nnv::decode_launch(h->shape, p, plan, false, static_cast<hipStream_t>(stream));
+  return nnv::decode_launch(h->shape, p, plan, false, h->device, static_cast<hipStream_t>(stream));
 }
 
 int32_t nnv_mlp_decode_binned_f32(const nnv_mlp_handle *h, const float *x_dev, int64_t n_rows,
@@ -338,7 +365,7 @@ int32_t nnv_mlp_decode_binned_f32(const nnv_mlp_handle *h, const float *x_dev, i
   p.n_bins = n_bins;
   p.rows_per_block = rows_per_block;
   p.first_row = first_row;
-  return nnv::decode_launch(h->shape, p, plan, false, static_cast<hipStream_t>(stream));
+  return nnv::decode_launch(h->shape, p, plan, false, h->device, static_cast<hipStream_t>(stream));
 }
 
 int32_t nnv_mlp_forward_f32(const nnv_mlp_handle *h, const float *x_dev, int64_t n_rows,
@@ -351,7 +378,7 @@ int32_t nnv_mlp_forward_f32(const nnv_mlp_handle *h, const float *x_dev, int64_t
   const nnv_status st = make_params(h, x_dev, n_rows, &p, &plan);
   if (st != NNV_OK) return st;
   p.act = out_dev;
-  return nnv::decode_launch(h->shape, p, plan, true, static_cast<hipStream_t>(stream));
+  return nnv::decode_launch(h->shape, p, plan, true, h->device, static_cast<hipStream_t>(stream));
 }
 
 int32_t nnv_awgn_generate_f32(int32_t code, int32_t tile_bits, int64_t n_rows, int64_t first_row,
@@ -400,12 +427,12 @@ int32_t nnv_mlp_decode_f32_timed(const nnv_mlp_handle *h, const float *x_dev, in
 int32_t nnv_mlp_launch_info(const nnv_mlp_handle *h, int64_t n_rows, int32_t *info_host) {
   if (!h || !info_host || n_rows < 0) return NNV_ERR_INVALID_ARGUMENT;
   LaunchPlan plan;
-  const nnv_status st = nnv::decode_plan(h->shape, n_rows, h->num_cus, h->lds_limit, &plan);
+  const nnv_status st = nnv::decode_plan(h->shape, n_rows, h->num_cus, h->lds_limit, h->threads, &plan);
   if (st != NNV_OK) return st;
   info_host[0] = plan.threads;
   info_host[1] = plan.blocks;
   info_host[2] = plan.lds_bytes;
-  info_host[3] = nnv::decode_kernel_vgprs(h->shape);
+  info_host[3] = h->vgprs;
   info_host[4] = plan.out_in_lds;
   info_host[5] = nnv::kRowsPerTile;
   info_host[6] = h->shape.depth;

@@ -82,6 +82,13 @@ inline float f16_to_f32(uint16_t h) {
 //                                         + 8((8s+e)>>2) + 4(lane>>5)  (accumulator register 8s+e)
 constexpr int kPrecF32 = 0;
 constexpr int kPrecF16x3 = 1;
+// fp32 mode: hidden activations travel as r = 1/(1+2^zeta) with tanh's affine map 1 - 2r folded
+// into the next layer's packed weights (as the f16x3 mode always does).  Kernel (act16) and packer
+// (pack_network) must agree; 0 only in A/B builds.
+#ifndef NNV_FOLD_F32
+#define NNV_FOLD_F32 1
+#endif
+constexpr bool kFoldF32 = NNV_FOLD_F32 != 0;
 constexpr int kFragGroupFloats = 256;
 constexpr int kRowsPerTile = 32;  // batch rows per wave tile (MFMA N dim)
 
@@ -139,15 +146,24 @@ struct LaunchPlan {
   int32_t out_lds_tiles;
 };
 
+// nnv_capi.hip: NNV_OK iff `device` is the calling thread's current HIP device.  Every launch entry
+// checks its handle's device first: a handle's packed network, kernel attributes and pointers belong to
+// the device it was packed for, and launching them on another one is a fault, not an error code.
+nnv_status check_current_device(int device);
+constexpr int kMaxDevices = 64;  // per-device kernel-attribute cache (one process may drive several GPUs)
+
 // nnv_mlp_decode.hip
 nnv_status decode_supported(const PackedShape &s);
+// threads: the workgroup size picked ONCE at prepack (decode_pick_threads) and kept in the handle, so a
+// launch is table lookups + hipLaunchKernel, without runtime attribute queries.
+int decode_pick_threads(const PackedShape &s);
 nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
-                       int lds_limit, LaunchPlan *plan);
+                       int lds_limit, int threads, LaunchPlan *plan);
 nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
-                         const LaunchPlan &plan, bool write_act,
+                         const LaunchPlan &plan, bool write_act, int device,
                          hipStream_t stream);
-int decode_kernel_vgprs(const PackedShape &s);
-nnv_status decode_prepare(const PackedShape &s, int num_cus, int lds_limit);
+int decode_kernel_vgprs(const PackedShape &s, int threads);
+nnv_status decode_prepare(const PackedShape &s, int num_cus, int lds_limit, int threads, int device);
 
 // nnv_dense.hip: layer-at-a-time path for wide networks
 constexpr int kDenseBM = 128, kDenseBN = 128, kDenseBK = 32;
@@ -231,4 +247,6 @@ struct nnv_mlp_handle {
   int device;
   int num_cus;
   int lds_limit;
+  int threads;  // workgroup size of the decode kernels, picked at prepack
+  int vgprs;    // of the decode instantiation (introspection)
 };

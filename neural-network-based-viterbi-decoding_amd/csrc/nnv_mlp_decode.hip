@@ -36,6 +36,9 @@
 #ifndef NNV_CLASS_GROUP
 #define NNV_CLASS_GROUP 2
 #endif
+#ifndef NNV_DEFER_ARGMAX
+#define NNV_DEFER_ARGMAX 1
+#endif
 
 namespace nnv {
 
@@ -174,17 +177,20 @@ __device__ __forceinline__ f32x16 init_acc(const float *bias_tile, int half) {
 // Hidden-layer activation as the NEXT layer consumes it.  In BOTH modes the hidden layers' packed
 // weights and biases carry the factor 2 log2(e) (prepack, computed in double), so the accumulator
 // holds zeta = 2 log2(e) z and tanh(z) = 1 - 2 / (1 + 2^zeta) needs no multiply in the tile loop.
-//  fp32 : a = tanh(z) = fma(-2, rcp(1 + exp2(zeta)), 1).
-//  f16x3: r = 1 / (1 + 2^zeta), i.e. tanh(z) = 1 - 2r with the affine map folded into the next
-//         layer's packed weights as well (W' = -2W, b' = b + sum_k W_k; pack_network_f16x3 in
-//         nnv_capi.hip): 3 VALU instructions per activation in the mode that is issue-bound.
+//  The activation handed on is r = 1 / (1 + 2^zeta), i.e. tanh(z) = 1 - 2r with the affine map folded
+//  into the next layer's packed weights as well (W' = -2W, b' = b + sum_k W_k, computed in double at
+//  prepack: pack_network / pack_network_f16x3 in nnv_capi.hip): 3 VALU instructions per activation
+//  (v_exp, v_add, v_rcp) instead of 4.  On gfx950 the fp32 MFMA does not co-execute with VALU work,
+//  so the 112 FMAs per tile this removes are ~1.4 % of the kernel time; outputs stay within 3e-6 of
+//  the float64 restatement (contract 1e-5).  kFoldF32 = false (-DNNV_FOLD_F32=0, A/B builds only)
+//  keeps a = tanh(z) = fma(-2, r, 1) between fp32 layers.
 //  Limits stay exact: zeta -> +inf gives rcp(inf) = 0 (tanh 1), -inf gives rcp(1) = 1 (tanh -1).
 template <int PREC>
 __device__ __forceinline__ void act16(f32x16 &acc) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r]));
-    if constexpr (PREC == kPrecF32) acc[r] = __builtin_fmaf(-2.0f, rr, 1.0f);
+    if constexpr (PREC == kPrecF32 && !kFoldF32) acc[r] = __builtin_fmaf(-2.0f, rr, 1.0f);
     else acc[r] = rr;
   }
 }
@@ -198,6 +204,7 @@ __device__ __forceinline__ void act16(f32x16 &acc) {
 // unsaturated z that round to the same fp32 tanh, |dtanh| < 6e-8, are told
 // apart here; that is far inside the 1e-5 near-tie rule of DESIGN.md.)
 constexpr float kTanhSat = 9.011f;
+constexpr bool kDeferArgmax = NNV_DEFER_ARGMAX != 0;
 
 template <int G1, bool VEC_ONLY>
 __device__ __forceinline__ void load_x(const DecodeParams &p, int64_t tile,
@@ -424,24 +431,38 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       ubuf[slot][0] = src[0];
       if constexpr (PREC != kPrecF32) ubuf[slot][1] = src[kFragGroupFloats / 4];
     };
-    // First maximum of this lane's 16 classes in ~51 VALU ops: the tile maximum by a
-    // v_max3 tree on the RAW pre-activations, clamped once (clamping is monotone, so
-    // clamp(max z) == max clamp(z)); then the smallest register index r with
-    // z_r >= m (equivalent to clamp(z_r) == m because m <= +sat; below -sat nothing
-    // matches and the tile's first class stands for the all-equal tile), by a
-    // descending select scan; then strict > against the earlier M-tiles (lower class indices).
+    // Running first maximum over the class tiles, index scan DEFERRED to the end of the row tile.
+    // Per class tile (~28 VALU ops): the tile maximum by a v_max3 tree on the RAW pre-activations,
+    // clamped once (clamping is monotone: clamp(max z) == max clamp(z)); strict > against the
+    // earlier M-tiles (lower class indices keep ties); the winner's 16 raw accumulators and its
+    // tile id are kept by conditional moves.  Once per row tile (epilogue, ~40 ops): the smallest
+    // register index r of the kept tile with z_r >= best (equivalent to clamp(z_r) == best because
+    // best <= +sat; if every class sits below -sat nothing matches and the tile's first class
+    // stands for the all-equal tile), by a descending select scan.  The scan used to run in every
+    // class tile (51 ops x 8 tiles; -DNNV_DEFER_ARGMAX=0 restores that for A/B builds).
+    f32x16 keep;
+    int btile = 0;
+    auto scan_first = [&](const f32x16 &acc, float m) -> unsigned {
+      unsigned t = 16u;
+#pragma unroll
+      for (int r = 15; r >= 0; --r) t = acc[r] >= m ? static_cast<unsigned>(r) : t;
+      return t == 16u ? 0u : t;
+    };
     auto argmax_tile = [&](const f32x16 &acc, int mt) {
       float m = __builtin_fmaxf(acc[0], acc[1]);
 #pragma unroll
       for (int r = 2; r < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, acc[r]), acc[r + 1]);
       m = __builtin_amdgcn_fmed3f(m, -kTanhSat, kTanhSat);
-      unsigned t = 16u;
-#pragma unroll
-      for (int r = 15; r >= 0; --r) t = acc[r] >= m ? static_cast<unsigned>(r) : t;
-      t = t == 16u ? 0u : t;
       const bool c = m > best;
       best = c ? m : best;
-      bidx = c ? 32 * mt + 4 * half + 8 * static_cast<int>(t >> 2) + static_cast<int>(t & 3u) : bidx;
+      if constexpr (kDeferArgmax) {
+        btile = c ? mt : btile;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep[r] = c ? acc[r] : keep[r];
+      } else {
+        const unsigned t = scan_first(acc, m);
+        bidx = c ? 32 * mt + 4 * half + 8 * static_cast<int>(t >> 2) + static_cast<int>(t & 3u) : bidx;
+      }
     };
     int mt0 = 0;
     if constexpr (LEAN) {
@@ -492,18 +513,18 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
           }
         }
       }
-      if (LEAN || ((mt + 1) * 32) <= p.n_classes) {
-        argmax_tile(acc, mt);
-      } else {  // last tile of a class count that is not a multiple of 32
+      if (!LEAN && ((mt + 1) * 32) > p.n_classes) {  // last tile of a class count that is not a multiple of 32
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ci = cbase + 8 * (r >> 2) + (r & 3);
-          const float zc = __builtin_amdgcn_fmed3f(acc[r], -kTanhSat, kTanhSat);
-          const bool c = (ci < p.n_classes) && (zc > best);
-          best = c ? zc : best;
-          bidx = c ? ci : bidx;
+          acc[r] = ci < p.n_classes ? acc[r] : -__builtin_inff();
         }
       }
+      argmax_tile(acc, mt);
+    }
+    if constexpr (kDeferArgmax) {
+      const unsigned t = scan_first(keep, best);
+      bidx = 32 * btile + 4 * half + 8 * static_cast<int>(t >> 2) + static_cast<int>(t & 3u);
     }
 
     NNV_STAMP(4);  // class layer
@@ -643,7 +664,7 @@ const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act, bool lean
 // Workgroup size: 1024 threads = 4 waves per SIMD (<= 128 VGPRs) when that
 // instantiation does not spill, else 512 (2 per SIMD).  NNV_THREADS overrides
 // (tuning / A-B runs only).
-int pick_threads(const PackedShape &s) {
+int pick_threads_impl(const PackedShape &s) {
   static const int forced = [] {
     const char *e = getenv("NNV_THREADS");
     const int v = e ? atoi(e) : 0;
@@ -666,8 +687,10 @@ nnv_status decode_supported(const PackedShape &s) {
   return find_kernel(s, 512, false) ? NNV_OK : NNV_ERR_UNSUPPORTED_SHAPE;
 }
 
-int decode_kernel_vgprs(const PackedShape &s) {
-  const KernelEntry *k = find_kernel(s, pick_threads(s), false);
+int decode_pick_threads(const PackedShape &s) { return pick_threads_impl(s); }
+
+int decode_kernel_vgprs(const PackedShape &s, int threads) {
+  const KernelEntry *k = find_kernel(s, threads, false);
   if (!k) return 0;
   hipFuncAttributes attr;
   if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) return 0;
@@ -675,7 +698,7 @@ int decode_kernel_vgprs(const PackedShape &s) {
 }
 
 nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
-                       int lds_limit, LaunchPlan *plan) {
+                       int lds_limit, int threads, LaunchPlan *plan) {
   if (!find_kernel(s, 512, false)) return NNV_ERR_UNSUPPORTED_SHAPE;
   const int64_t base_floats = s.hid_floats + s.bias_floats;
   if (base_floats * 4 + kLdsTailBytes > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
@@ -686,7 +709,7 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
   plan->out_lds_tiles = static_cast<int32_t>(fit);
   plan->out_in_lds = fit == s.mt_out ? 1 : 0;
   plan->lds_bytes = static_cast<int32_t>(base_floats * 4 + fit * per_tile_bytes) + kLdsTailBytes;  // + work counter, bin counters
-  plan->threads = pick_threads(s);
+  plan->threads = threads;
   // Persistent: one workgroup per CU.  Small batches are spread over as many CUs as they have
   // tiles (one busy wave per CU, the others find no work and leave) rather than packed 16 tiles to
   // a CU: BASELINE configs[0] (2,000 rows) 107 -> 39 us per launch, 20,000 rows 110 -> 63 us.
@@ -699,39 +722,43 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
 }
 
 namespace {
-// dynamic LDS above the default cap must be opted into, once per kernel
-nnv_status ensure_lds_optin(const KernelEntry *k, int lds_bytes) {
-  static int lds_set[sizeof(kKernels) / sizeof(kKernels[0])] = {0};
+// dynamic LDS above the default cap must be opted into, once per (device, kernel): the attribute
+// belongs to the function as loaded on ONE device
+nnv_status ensure_lds_optin(int device, const KernelEntry *k, int lds_bytes) {
+  constexpr int kN = sizeof(kKernels) / sizeof(kKernels[0]);
+  static int lds_set[kMaxDevices][kN] = {};
   static std::mutex mu;  // prepack / launches may come from several host threads
+  if (device < 0 || device >= kMaxDevices) return NNV_ERR_INVALID_ARGUMENT;
   const std::lock_guard<std::mutex> lock(mu);
   const int idx = static_cast<int>(k - kKernels);
-  if (lds_set[idx] < lds_bytes) {
+  if (lds_set[device][idx] < lds_bytes) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k->fn),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
       return NNV_ERR_HIP;
-    lds_set[idx] = lds_bytes;
+    lds_set[device][idx] = lds_bytes;
   }
   return NNV_OK;
 }
 }  // namespace
 
-// Called from prepack: every attribute a launch of this network needs is set here, so that the
-// launches themselves are pure kernel launches (capturable into a HIP graph from the first call).
-nnv_status decode_prepare(const PackedShape &s, int num_cus, int lds_limit) {
+// Called from prepack (on the handle's device): every attribute a launch of this network needs is set
+// here, so that the launches themselves are pure kernel launches (capturable into a HIP graph from the
+// first call).
+nnv_status decode_prepare(const PackedShape &s, int num_cus, int lds_limit, int threads, int device) {
   LaunchPlan plan;
-  const nnv_status st = decode_plan(s, 1 << 20, num_cus, lds_limit, &plan);
+  const nnv_status st = decode_plan(s, 1 << 20, num_cus, lds_limit, threads, &plan);
   if (st != NNV_OK) return st;
   for (const int which : {0, 1, 2}) {  // decode, debug forward, lean decode
     const KernelEntry *k = find_kernel(s, which == 1 ? 512 : plan.threads, which == 1, which == 2);
     if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
-    const nnv_status e = ensure_lds_optin(k, plan.lds_bytes);
+    const nnv_status e = ensure_lds_optin(device, k, plan.lds_bytes);
     if (e != NNV_OK) return e;
   }
   return NNV_OK;
 }
 
 nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
-                         const LaunchPlan &plan, bool write_act,
+                         const LaunchPlan &plan, bool write_act, int device,
                          hipStream_t stream) {
   const int nt = write_act ? 512 : plan.threads;
   static const bool no_lean = getenv("NNV_NO_LEAN") != nullptr;  // A/B runs only
@@ -739,7 +766,7 @@ nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
   const KernelEntry *k = find_kernel(s, nt, write_act, lean);
   if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
   {
-    const nnv_status e = ensure_lds_optin(k, plan.lds_bytes);
+    const nnv_status e = ensure_lds_optin(device, k, plan.lds_bytes);
     if (e != NNV_OK) return e;
   }
   int blocks = plan.blocks;

@@ -412,6 +412,10 @@ int32_t nnv_seq2seq_forward_f32(const nnv_seq2seq_handle *h, const float *enc_in
                                 int32_t n_bits, uint64_t *counters_dev, void *stream) {
   if (!h || batch < 0 || t_enc < 0 || t_dec < 0 || n_bits < 0) return NNV_ERR_INVALID_ARGUMENT;
   if (batch == 0) return NNV_OK;
+  {
+    const nnv_status dv = nnv::check_current_device(h->device);
+    if (dv != NNV_OK) return dv;
+  }
   if ((t_enc > 0 && !enc_in_dev) || (t_dec > 0 && !dec_in_dev)) return NNV_ERR_INVALID_ARGUMENT;
   if (counters_dev && !info_dev) return NNV_ERR_INVALID_ARGUMENT;
   if ((bits_dev || info_dev) && n_bits > t_dec) return NNV_ERR_INVALID_ARGUMENT;

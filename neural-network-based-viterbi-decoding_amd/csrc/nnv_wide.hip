@@ -19,6 +19,7 @@ struct nnv_wide_handle {
   float *dev;                         // all packed weights and biases
   int64_t w_off[NNV_WIDE_MAX_LAYERS], b_off[NNV_WIDE_MAX_LAYERS];
   int32_t max_mpad;
+  int32_t device;                     // the HIP device the network was packed for
 };
 
 namespace {
@@ -82,6 +83,7 @@ int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out) {
   nnv_wide_handle *h = new (std::nothrow) nnv_wide_handle;
   if (!h) return NNV_ERR_OUT_OF_MEMORY;
   memset(h, 0, sizeof(*h));
+  h->device = dev;
   h->depth = net->depth;
   h->act = net->activation == NNV_ACT_RELU ? 2 : 1;
   for (int l = 0; l <= net->depth; ++l) h->dims[l] = net->dims[l];
@@ -166,6 +168,10 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev, int64_
   if (!h || n_rows < 0 || row_stride < 1) return NNV_ERR_INVALID_ARGUMENT;
   if (n_rows == 0) return NNV_OK;
   if (!x_dev || !workspace_dev) return NNV_ERR_INVALID_ARGUMENT;
+  {
+    const nnv_status dv = nnv::check_current_device(h->device);
+    if (dv != NNV_OK) return dv;
+  }
   if (reinterpret_cast<uintptr_t>(x_dev) % 8 != 0 || (row_stride % 2) != 0) return NNV_ERR_INVALID_ARGUMENT;
   const int64_t per_row = 2LL * h->max_mpad * static_cast<int64_t>(sizeof(float));
   int64_t chunk = workspace_bytes / per_row / 128 * 128;

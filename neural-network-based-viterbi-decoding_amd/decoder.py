@@ -10,8 +10,10 @@ Replaces the reference's ``Session.run`` of
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
+import weakref
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -585,28 +587,91 @@ def generate_awgn_blocks(code: str, tile_bits: int, n_rows: int, sigma, seed: in
 
 
 # ---------------------------------------------------------------------------
-# torch custom op:  torch.ops.nnviterbi.mlp_decode
+# torch custom ops:  torch.ops.nnviterbi.mlp_decode / mlp_forward
+#   one schema, two dispatch keys (SURVEY.md 8b "Operator"):
+#     CUDA (= HIP on ROCm): the fused gfx950 kernel through the C ABI
+#     CPU: the same chain in plain torch ops (BASELINE configs[0] "plumbing, no GPU";
+#          the reference's own call is a CPU call, src/fnn_viterbi.py:606-610)
 # ---------------------------------------------------------------------------
-_PACK_CACHE: Dict[tuple, PackedMLP] = {}
+class _PackEntry:
+    __slots__ = ("net", "refs", "stamps")
+
+    def __init__(self, net, refs, stamps):
+        self.net, self.refs, self.stamps = net, refs, stamps
+
+
+# key: (device, precision, id of every weight/bias tensor object).  An entry is valid only while
+# every one of those tensor OBJECTS is still alive and unmodified: it holds a weakref to each (a
+# dead tensor evicts the entry from the weakref callback, which also frees the packed network's
+# HBM) plus its (data_ptr, _version) at pack time.  Raw addresses alone are not a key: the caching
+# allocator hands a freed address to the next same-sized checkpoint with _version 0 again.
+_PACK_CACHE: "collections.OrderedDict[tuple, _PackEntry]" = collections.OrderedDict()
+_PACK_CACHE_MAX = 16
+
+
+def _evict(key) -> None:
+    e = _PACK_CACHE.pop(key, None)
+    if e is not None:
+        e.net.close()
+
+
+def clear_pack_cache() -> None:
+    """Drop every network the torch ops have packed (e.g. after writing weights through ``.data``,
+    which does not bump ``_version``)."""
+    for key in list(_PACK_CACHE):
+        _evict(key)
 
 
 def _cached_pack(weights: List[torch.Tensor], biases: List[torch.Tensor], device) -> PackedMLP:
-    key = (str(device),) + tuple((t.data_ptr(), t._version, tuple(t.shape))
-                                 for t in list(weights) + list(biases))
-    net = _PACK_CACHE.get(key)
-    if net is None:
-        if len(_PACK_CACHE) > 16:
-            _PACK_CACHE.clear()
-        net = PackedMLP(weights, biases, device=device)
-        _PACK_CACHE[key] = net
+    tensors = list(weights) + list(biases)
+    precision = _resolve_precision(None)
+    key = (str(device), precision) + tuple(id(t) for t in tensors)
+    stamps = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    e = _PACK_CACHE.get(key)
+    if e is not None:
+        if e.stamps == stamps and all(r() is t for r, t in zip(e.refs, tensors)):
+            _PACK_CACHE.move_to_end(key)
+            return e.net
+        _evict(key)                                   # same ids, other tensors / modified in place
+    while len(_PACK_CACHE) >= _PACK_CACHE_MAX:
+        _evict(next(iter(_PACK_CACHE)))               # least recently used
+    net = PackedMLP(weights, biases, device=device, precision=precision)
+    refs = [weakref.ref(t, lambda _r, k=key: _evict(k)) for t in tensors]
+    _PACK_CACHE[key] = _PackEntry(net, refs, stamps)
     return net
+
+
+def _forward_torch(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.Tensor]) -> torch.Tensor:
+    """multilayer_perceptron in plain torch ops, op order of src/fnn_viterbi.py:495-508 per
+    layer: matmul, add, tanh (the class layer too).  The CPU dispatch key's arithmetic."""
+    h = x
+    for W, b in zip(weights, biases):
+        h = torch.tanh(torch.add(torch.matmul(h, W), b))
+    return h
+
+
+def _check_op_args(x, weights, biases, tile_bits=None, labels=None):
+    if x.dtype != torch.float32 or x.dim() != 2:
+        raise ValueError("x must be float32 [N, n_in]")
+    if len(weights) != len(biases) or not (2 <= len(weights) <= _cabi.NNV_MAX_LAYERS):
+        raise ValueError("need 2..4 dense layers with one bias vector each")
+    n_prev = x.shape[1]
+    for W, b in zip(weights, biases):
+        if W.dim() != 2 or W.shape[0] != n_prev or b.dim() != 1 or b.shape[0] != W.shape[1] \
+                or W.dtype != torch.float32 or b.dtype != torch.float32:
+            raise ValueError("inconsistent layer shapes / dtypes")
+        n_prev = W.shape[1]
+    if tile_bits is not None and (tile_bits < 1 or tile_bits > 30 or (1 << tile_bits) < n_prev):
+        raise ValueError("tile_bits must satisfy 2**tile_bits >= n_classes")
+    if labels is not None and (labels.dtype != torch.int32 or tuple(labels.shape) != (x.shape[0],)):
+        raise ValueError("labels must be int32 [N] on x's device")
 
 
 @torch.library.custom_op("nnviterbi::mlp_decode", mutates_args=(), device_types="cuda")
 def mlp_decode(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.Tensor],
                tile_bits: int, labels: Optional[torch.Tensor] = None
                ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """(cls int64 [N], bits uint8 [N, b], counters int64 [4]) — HIP only."""
+    """(cls int64 [N], bits uint8 [N, b], counters int64 [4]) - HIP kernel."""
     net = _cached_pack(list(weights), list(biases), x.device)
     r = net.decode(x, labels=labels, tile_bits=tile_bits, want_cls32=False,
                    want_cls64=True, want_bits=True)
@@ -614,6 +679,26 @@ def mlp_decode(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.
     if counters is None:
         counters = torch.zeros(4, dtype=torch.int64, device=x.device)
     return r["cls64"], r["bits"], counters
+
+
+@mlp_decode.register_kernel("cpu")
+def _mlp_decode_cpu(x, weights, biases, tile_bits, labels=None):
+    """CPU dispatch key: forward in torch ops, first-max argmax (src/fnn_viterbi.py:606-610),
+    MSB-first bits (:648-651), {bit_errors, frame_errors, total_bits, total_frames} (:639,654-671)."""
+    _check_op_args(x, weights, biases, tile_bits, labels)
+    n = x.shape[0]
+    cls = torch.argmax(_forward_torch(x, list(weights), list(biases)), dim=1) if n else \
+        torch.empty(0, dtype=torch.int64)
+    shifts = torch.arange(tile_bits - 1, -1, -1, dtype=torch.int64)
+    bits = ((cls[:, None] >> shifts[None, :]) & 1).to(torch.uint8)
+    counters = torch.zeros(4, dtype=torch.int64)
+    if labels is not None:
+        diff = cls ^ labels.to(torch.int64)
+        counters[0] = ((diff[:, None] >> shifts[None, :]) & 1).sum()
+        counters[1] = (diff != 0).sum()
+        counters[2] = n * tile_bits
+        counters[3] = n
+    return cls, bits, counters
 
 
 @mlp_decode.register_fake
@@ -626,8 +711,14 @@ def _(x, weights, biases, tile_bits, labels=None):
 @torch.library.custom_op("nnviterbi::mlp_forward", mutates_args=(), device_types="cuda")
 def mlp_forward(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.Tensor]) -> torch.Tensor:
     """multilayer_perceptron(x, weights, biases) (src/fnn_viterbi.py:471-510): the tanh'd class layer
-    [N, n_classes] float32 — debug / parity op, HIP only."""
+    [N, n_classes] float32 - debug / parity op."""
     return _cached_pack(list(weights), list(biases), x.device).forward(x)
+
+
+@mlp_forward.register_kernel("cpu")
+def _mlp_forward_cpu(x, weights, biases):
+    _check_op_args(x, weights, biases)
+    return _forward_torch(x, list(weights), list(biases))
 
 
 @mlp_forward.register_fake

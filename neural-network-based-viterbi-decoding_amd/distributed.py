@@ -29,11 +29,14 @@ def block_shard(n_blocks: int, rank: int, world_size: int) -> Tuple[int, int]:
     return first, count
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+def init_from_env(backend: Optional[str] = None,
+                  device_index: Optional[int] = None) -> Tuple[int, int, int]:
     """Join the process group described by torchrun's environment.
 
     Returns (rank, local_rank, world_size); a no-op for a single process.
     backend: "nccl" (= RCCL on ROCm) when CUDA/HIP is available, else "gloo".
+    device_index: the ONE HIP device this rank uses (default LOCAL_RANK); the RCCL group is bound
+    to exactly that device, so the caller's allocations and the collective cannot disagree.
     """
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -46,12 +49,27 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            idx = local_rank if device_index is None else int(device_index)
+            if idx >= torch.cuda.device_count():
+                raise RuntimeError(f"rank {rank}: device {idx} requested, "
+                                   f"{torch.cuda.device_count()} visible (RCCL needs one GPU per rank)")
+            torch.cuda.set_device(idx)
             dist.init_process_group(backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+                                    device_id=torch.device("cuda", idx))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def gather_ints(value: int, device=None, group=None) -> list:
+    """[value of rank 0, value of rank 1, ...] on every rank (all_gather of one int64)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return [int(value)]
+    on_host = device is None or dist.get_backend(group) == "gloo"
+    t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if on_host else device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return [int(o.item()) for o in out]
 
 
 def all_reduce_counters(counters: torch.Tensor, group=None) -> torch.Tensor:

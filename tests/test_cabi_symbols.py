@@ -80,3 +80,17 @@ def test_unsupported_shape_is_reported_before_touching_the_device(lib):
     assert lib.nnv_mlp_prepack(ctypes.byref(d), ctypes.byref(h)) == 2  # UNSUPPORTED_SHAPE
     d.depth = 7
     assert lib.nnv_mlp_prepack(ctypes.byref(d), ctypes.byref(h)) == 2
+
+
+def test_device_rule_status_codes(lib):
+    """nnv_check_device is the rule every launch entry applies to its handle's device first.
+    Without a HIP device it reports NO_DEVICE; with one, the current device is OK and any other
+    index is INVALID_ARGUMENT (so a handle packed for another GPU is refused, not launched)."""
+    if lib.nnv_device_count() == 0:
+        assert lib.nnv_check_device(0) == 3                  # NNV_ERR_NO_DEVICE
+    else:
+        import torch
+        cur = torch.cuda.current_device()
+        assert lib.nnv_check_device(cur) == 0
+        assert lib.nnv_check_device(cur + 1) == 1            # NNV_ERR_INVALID_ARGUMENT
+    assert b"another device" in lib.nnv_status_string(1)

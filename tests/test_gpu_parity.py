@@ -599,3 +599,34 @@ def test_repeated_launches_are_bitwise_identical(cuda_device, precision):
         r = net.decode(x, labels=lab, tile_bits=b)
         assert torch.equal(r["cls32"], first["cls32"]) and torch.equal(r["counters"], first["counters"])
     net.close()
+
+
+# ------------------------------------------------------------------ device affinity of the C ABI
+def test_handle_device_rule(cuda_device):
+    from nnviterbi_amd import _cabi
+    lib = _cabi.load_library()
+    assert lib.nnv_check_device(0) == 0 and lib.nnv_check_device(1) == 1
+
+
+def test_handle_packed_on_one_gpu_is_refused_on_another(cuda_device):
+    """A C caller that switched devices gets NNV_ERR_INVALID_ARGUMENT, not a launch with foreign
+    pointers; and a second device in the same process gets its own LDS opt-in (per-device cache)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the gpurun box has one)")
+    import ctypes
+    from nnviterbi_amd import _cabi
+    Ws, bs = _net([16, 128, 64, 32, 256], 3)
+    net0 = PackedMLP(Ws, bs, device="cuda:0")
+    x0 = torch.randn(1000, 16, device="cuda:0")
+    cls0 = torch.empty(1000, dtype=torch.int32, device="cuda:0")
+    lib = _cabi.load_library()
+    with torch.cuda.device(1):
+        st = lib.nnv_mlp_decode_f32(net0._handle, ctypes.c_void_p(x0.data_ptr()), 1000, 8, None,
+                                    ctypes.c_void_p(cls0.data_ptr()), None, None, None, None)
+        assert st == 1
+    net1 = PackedMLP(Ws, bs, device="cuda:1")          # 84 KB of LDS: needs the opt-in on device 1 too
+    r1 = net1.decode(x0.to("cuda:1"), tile_bits=8)
+    r0 = net0.decode(x0, tile_bits=8)
+    assert torch.equal(r0["cls32"].cpu(), r1["cls32"].cpu())
+    net0.close()
+    net1.close()

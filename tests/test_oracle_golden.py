@@ -135,3 +135,50 @@ def test_argmax_first_maximum_rule():
     b = [np.zeros(4, np.float32), np.full(4, 30.0, np.float32)]
     r = O.decode_c(np.ones((3, 2), np.float32), W, b, 2)
     assert r["cls"].tolist() == [0, 0, 0]
+
+
+# ---------------------------------------------------------------- triangulation (parity unpinned)
+def _trained_net():
+    import os
+    ck = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                              "neural-network-based-viterbi-decoding_amd", "weights",
+                              "fnn_133171_b8_2dB.npz"), allow_pickle=False)
+    return ([ck[k] for k in ("weights_h1", "weights_h2", "weights_h3", "weights_out")],
+            [ck[k] for k in ("bias_h1", "bias_h2", "bias_h3", "bias_out")])
+
+
+def _triangulate(x, Ws, bs, b):
+    """numpy-f32, C-f32, torch-CPU-f32 and torch-CPU-f64 against the numpy float64 chain: outputs
+    within 1e-5, class differences only on rows whose float64 top-2 margin is below 1e-5.
+    Returns the pairwise flip counts (reported in DESIGN.md section 2 via tools/flip_rates.py)."""
+    import torch
+    from oracle import torch_cpu as T
+    c64, _, o64 = O.decode(x, Ws, bs, b, np.float64)
+    margin = O.top2_margin(o64)
+    c = O.decode_c(x, Ws, bs, b, want_act=True, want_bits=False)
+    impl = {"numpy_f32": O.decode(x, Ws, bs, b, np.float32)[::2], "c_f32": (c["cls"], c["act"]),
+            "torch_f32": T.decode(x, Ws, bs, torch.float32), "torch_f64": T.decode(x, Ws, bs, torch.float64)}
+    for name, (cls, out) in impl.items():
+        assert np.abs(out - o64).max() < (1e-12 if name == "torch_f64" else 1e-5), name
+        bad = cls != c64
+        assert not bad.any() or margin[bad].max() < 1e-5, name
+    names = list(impl)
+    return {(p, q): int((impl[p][0] != impl[q][0]).sum()) for i, p in enumerate(names) for q in names[i + 1:]}
+
+
+@pytest.mark.parametrize("name,depth,b", CASES)
+def test_torch_cpu_triangulates_the_fixture_nets(forward_golden, name, depth, b):
+    """The one independent fp32 implementation importable here (PyTorch CPU kernels, op order
+    matmul -> add -> tanh of src/fnn_viterbi.py:495-508) obeys the same rules as our own
+    restatements.  This narrows, it does not pin: TensorFlow's kernels cannot be run (parity unpinned)."""
+    Ws, bs, x, _ = _case(forward_golden, name, depth)
+    flips = _triangulate(x, Ws, bs, b)
+    assert max(flips.values()) <= max(2, len(x) // 1000)
+
+
+def test_torch_cpu_triangulates_the_trained_net():
+    from oracle import awgn_model
+    Ws, bs = _trained_net()
+    x, _ = awgn_model.generate("133171", 8, 100_000, O.sigma_from_snr_db(2.0), 20240607, rows_per_block=8)
+    flips = _triangulate(x.astype(np.float32), Ws, bs, 8)
+    assert max(flips.values()) <= 5          # measured at 2 M rows: <= 2 (profiles/r02/flip_rates.json)

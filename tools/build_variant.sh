@@ -1,0 +1,21 @@
+#!/bin/bash
+# Usage: tools/build_variant.sh <name> [extra hipcc flags...]
+# Builds neural-network-based-viterbi-decoding_amd/ab_<name>.so from the current sources with extra
+# flags (e.g. -DNNV_DEFER_ARGMAX=0) in a scratch object directory; for tools/ab_bench.sh A/B runs.
+set -e
+name=$1; shift
+here=$(cd "$(dirname "$0")/.." && pwd)
+src=$here/neural-network-based-viterbi-decoding_amd/csrc
+obj=/tmp/nnv_variant_$name
+mkdir -p $obj
+pids=()
+for f in nnv_mlp_decode nnv_generator nnv_capi nnv_dense nnv_dense_f16x3 nnv_wide nnv_seq2seq; do
+  extra=""
+  [ $f = nnv_seq2seq ] && extra="-fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form"
+  [ $f = nnv_dense ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
+  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$here/include -I$src -Wall -Wno-unused-result $extra "$@" -c $src/$f.hip -o $obj/$f.o &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $here/neural-network-based-viterbi-decoding_amd/ab_$name.so $obj/*.o
+echo "built ab_$name.so"
