@@ -138,6 +138,31 @@ int32_t nnv_mlp_decode_f32(const nnv_mlp_handle *h, const float *x_dev,
                            uint64_t *counters_dev, void *stream);
 
 /*
+ * The reference's own call shape: HOST arrays in, HOST predictions out,
+ *   predictions = predictions_tensor.eval(feed_dict={x: test_set})
+ *     src/fnn_viterbi.py:606-610 (test_set is a numpy array; so are the results),
+ * as one SYNCHRONOUS call.  The rows are streamed through a ring of page-locked
+ * staging slots owned by the handle (allocated by the first call, reused by
+ * later ones, released by nnv_mlp_free): pageable -> pinned copies on
+ * `n_threads` host threads, H2D DMA, the fused decode launch and the D2H of the
+ * classes run concurrently on different chunks, so the call is bound by the
+ * host link (4 dims[0] + 4 bytes per row), not by staging.
+ *  x_host        [n_rows][dims[0]] fp32, any (pageable) host memory
+ *  labels_host   nullable [n_rows] int32
+ *  cls32_host / cls64_host  nullable [n_rows] outputs
+ *  counters_host nullable uint64[4], ADDED to; requires labels_host
+ *  chunk_rows    rows per pipeline stage (0 = 2^21)
+ *  n_threads     staging threads (0 = the CPUs this process may use, <= 16)
+ * Calls on one handle are serialised.  Must be called with the handle's device
+ * current.  Uses its own internal streams.
+ */
+int32_t nnv_mlp_decode_host_f32(nnv_mlp_handle *h, const float *x_host,
+                                int64_t n_rows, int32_t tile_bits,
+                                const int32_t *labels_host, int32_t *cls32_host,
+                                int64_t *cls64_host, uint64_t *counters_host,
+                                int64_t chunk_rows, int32_t n_threads);
+
+/*
  * The same launch with error counters kept PER SNR BIN, for mixed-SNR sweeps
  * (BASELINE config 4; the reference evaluates one SNR per run,
  * src/fnn_viterbi_mixed_snr.py:452-460,813-845): row r of this call belongs to
@@ -240,6 +265,48 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev,
                             float *act_dev, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Bit-wise decoder BANK: the reference trains one small ReLU network per
+ * information-bit position (`bit_position`),
+ *   2(6+L) -> n_hidden_1 (30) -> 2, ReLU after both layers, argmax = the bit
+ *   src/fnn_viterbi_bitwise.py:326-399 (build_network), :503-505 (eval)
+ * and decodes a block by running them one after the other over the same
+ * received rows.  The bank stacks the P first layers into one fp32-MFMA GEMM
+ * (32 columns per position) and finishes each position's 2-logit head in the
+ * GEMM epilogue: one launch, every row read once per 4 positions' tile, the
+ * hidden activations never leave the chip.
+ * ------------------------------------------------------------------------ */
+typedef struct nnv_bitwise_desc {
+  int32_t n_input;        /* 2 (constraint_length + block_length); even           */
+  int32_t n_hidden;       /* n_hidden_1 <= 32 (reference default 30)               */
+  int32_t n_positions;    /* P networks                                            */
+  const float *W1_host;   /* [P][n_input][n_hidden]  weights['h1'] of each network */
+  const float *b1_host;   /* [P][n_hidden]           biases['b1']                  */
+  const float *Wout_host; /* [P][n_hidden][2]        weights['out']                */
+  const float *bout_host; /* [P][2]                  biases['out']                 */
+} nnv_bitwise_desc;
+
+typedef struct nnv_bitwise_handle nnv_bitwise_handle;
+
+int32_t nnv_bitwise_prepack(const nnv_bitwise_desc *net, nnv_bitwise_handle **out);
+int32_t nnv_bitwise_free(nnv_bitwise_handle *h);
+
+/*
+ * Replaces P runs of  predictions = tf.argmax(pred, 1).eval({x: test_encoded})
+ * (src/fnn_viterbi_bitwise.py:503-505), one per trained bit position.
+ *  x_dev       [n_rows][n_input] fp32, 8-byte aligned (the noisy codewords)
+ *  bits_dev    [P][n_rows] uint8 out: position-major, i.e. one prediction vector
+ *              per network; first maximum on ties (both outputs ReLU'd to 0 -> bit 0)
+ *  act_dev     nullable [P][n_rows][2] fp32 out: the ReLU'd outputs (parity)
+ *  labels_dev  nullable [P][n_rows] uint8 true bits (test_info[:, bit_position])
+ *  errors_dev  nullable uint64[P] wrong decisions per position, ACCUMULATED;
+ *              needs labels_dev
+ */
+int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev,
+                               int64_t n_rows, uint8_t *bits_dev, float *act_dev,
+                               const uint8_t *labels_dev, uint64_t *errors_dev,
+                               void *stream);
+
+/* ------------------------------------------------------------------------
  * Recurrent decoder (LSTM encoder -> LSTM decoder -> linear), the inference
  * tensors of build_seq2seq_model, src/rnn_viterbi.py:235-340:
  *   encoder LSTMCell(H) + dynamic_rnn over encoder_inputs      :289-297
@@ -308,7 +375,8 @@ int32_t nnv_mlp_decode_f32_timed(const nnv_mlp_handle *h, const float *x_dev,
                                  int32_t iters, float *elapsed_ms_host);
 
 /* Introspection: fills info_host[0..7] = {threads per workgroup, workgroups
- * launched for n_rows, dynamic LDS bytes, VGPRs (0 if unknown), weights
+ * launched for n_rows, dynamic LDS bytes and VGPRs (0 if unknown) of the kernel
+ * variant a classes+counters call on aligned rows gets, weights
  * resident in LDS (1/0 for the output layer), rows per wave tile, depth,
  * n_classes}; info_host[8] = precision; info_host[9] = class-layer M-tiles (32
  * classes each) resident in LDS, the rest being streamed from L2 (info_host must

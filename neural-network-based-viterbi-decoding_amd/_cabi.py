@@ -25,10 +25,12 @@ NNV_PRECISION = {"f32": 0, "f16x3": 1}
 EXPORTED_SYMBOLS = (
     "nnv_abi_version", "nnv_status_string", "nnv_device_count", "nnv_check_device",
     "nnv_mlp_prepack", "nnv_mlp_prepack_ex", "nnv_mlp_free", "nnv_mlp_decode_f32", "nnv_mlp_decode_binned_f32",
+    "nnv_mlp_decode_host_f32",
     "nnv_mlp_forward_f32", "nnv_awgn_generate_f32",
     "nnv_mlp_decode_f32_timed", "nnv_mlp_launch_info",
     "nnv_wide_prepack", "nnv_wide_free", "nnv_wide_workspace_bytes", "nnv_wide_decode_f32",
     "nnv_seq2seq_prepack", "nnv_seq2seq_free", "nnv_seq2seq_forward_f32",
+    "nnv_bitwise_prepack", "nnv_bitwise_free", "nnv_bitwise_decode_f32",
 )
 
 
@@ -64,6 +66,18 @@ class Seq2SeqDesc(ctypes.Structure):
         ("dec_bias", ctypes.c_void_p),
         ("proj_w", ctypes.c_void_p),
         ("proj_b", ctypes.c_void_p),
+    ]
+
+
+class BitwiseDesc(ctypes.Structure):
+    _fields_ = [
+        ("n_input", ctypes.c_int32),
+        ("n_hidden", ctypes.c_int32),
+        ("n_positions", ctypes.c_int32),
+        ("W1_host", ctypes.c_void_p),
+        ("b1_host", ctypes.c_void_p),
+        ("Wout_host", ctypes.c_void_p),
+        ("bout_host", ctypes.c_void_p),
     ]
 
 
@@ -121,6 +135,10 @@ def load_library() -> ctypes.CDLL:
     lib.nnv_mlp_decode_f32.argtypes = [
         c.c_void_p, c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_void_p,
         c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.nnv_mlp_decode_host_f32.restype = c.c_int32
+    lib.nnv_mlp_decode_host_f32.argtypes = [
+        c.c_void_p, c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
+        c.c_int64, c.c_int32]
     lib.nnv_mlp_decode_binned_f32.restype = c.c_int32
     lib.nnv_mlp_decode_binned_f32.argtypes = [
         c.c_void_p, c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_void_p,
@@ -156,6 +174,13 @@ def load_library() -> ctypes.CDLL:
     lib.nnv_seq2seq_forward_f32.argtypes = [
         c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int64,
         c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p, c.c_void_p]
+    lib.nnv_bitwise_prepack.restype = c.c_int32
+    lib.nnv_bitwise_prepack.argtypes = [c.POINTER(BitwiseDesc), c.POINTER(c.c_void_p)]
+    lib.nnv_bitwise_free.restype = c.c_int32
+    lib.nnv_bitwise_free.argtypes = [c.c_void_p]
+    lib.nnv_bitwise_decode_f32.restype = c.c_int32
+    lib.nnv_bitwise_decode_f32.argtypes = [
+        c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
     if lib.nnv_abi_version() != NNV_ABI_VERSION:
         raise NNViterbiError(
             f"ABI mismatch: library {lib.nnv_abi_version()} != binding {NNV_ABI_VERSION}")

@@ -1,0 +1,125 @@
+// C ABI of the bit-wise decoder BANK: P independent  n_input -> n_hidden (ReLU) -> 2 (ReLU) -> argmax
+// networks, one per information-bit position, evaluated on the same received rows in ONE launch.
+//
+// The reference trains and evaluates one such network per `bit_position`
+// (src/fnn_viterbi_bitwise.py:326-399 build_network, :504-505 argmax eval): decoding a block of L
+// bits is L separate Session.runs over the same [N, 2(6+L)] matrix.  Here the P first layers are
+// stacked into one [n_input -> 32 P] GEMM (32 columns per position, n_hidden <= 32 used) on the fp32
+// matrix cores and each position's 2-logit head is finished in the GEMM epilogue
+// (dense_tanh_kernel<.., HEAD> in nnv_dense.hip): every row of x is read once per 4 positions' tile
+// from L2/HBM instead of once per position per launch, the hidden matrix never reaches HBM, and one
+// decided bit per (position, row) is written.  Host side only in this file.
+#include <new>
+#include <vector>
+
+#include "nnv_internal.h"
+
+struct nnv_bitwise_handle {
+  int32_t n_input, n_hidden, n_pos;
+  int32_t kpad;    // n_input rounded up to the GEMM k-tile
+  int32_t bn;      // 128 (4 positions per column block) or 32 (a single position)
+  int32_t mpad;    // 32 * positions rounded up to bn
+  int32_t device;
+  float *dev;      // Wt [mpad][kpad] | bias [mpad] | head_w [n_pos][32][2] | head_b [n_pos][2]
+  int64_t off_bias, off_hw, off_hb;
+};
+
+extern "C" {
+
+int32_t nnv_bitwise_prepack(const nnv_bitwise_desc *d, nnv_bitwise_handle **out) {
+  if (!d || !out) return NNV_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (d->n_input < 2 || d->n_input > 16384 || (d->n_input & 1)) return NNV_ERR_INVALID_ARGUMENT;
+  if (d->n_hidden < 1 || d->n_positions < 1) return NNV_ERR_INVALID_ARGUMENT;
+  if (d->n_hidden > 32 || d->n_positions > 65536) return NNV_ERR_UNSUPPORTED_SHAPE;
+  if (!d->W1_host || !d->b1_host || !d->Wout_host || !d->bout_host) return NNV_ERR_INVALID_ARGUMENT;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+    return NNV_ERR_NO_DEVICE;
+  if (!strstr(prop.gcnArchName, "gfx950")) return NNV_ERR_NO_DEVICE;
+
+  nnv_bitwise_handle *h = new (std::nothrow) nnv_bitwise_handle;
+  if (!h) return NNV_ERR_OUT_OF_MEMORY;
+  h->n_input = d->n_input;
+  h->n_hidden = d->n_hidden;
+  h->n_pos = d->n_positions;
+  h->device = dev;
+  h->kpad = (d->n_input + nnv::kDenseBK - 1) / nnv::kDenseBK * nnv::kDenseBK;
+  h->bn = d->n_positions == 1 ? 32 : 128;
+  h->mpad = (32 * d->n_positions + h->bn - 1) / h->bn * h->bn;
+  const int64_t K = d->n_input, H = d->n_hidden, P = d->n_positions;
+  h->off_bias = static_cast<int64_t>(h->mpad) * h->kpad;
+  h->off_hw = h->off_bias + h->mpad;
+  h->off_hb = h->off_hw + P * 64;
+  std::vector<float> host(static_cast<size_t>(h->off_hb + 2 * P), 0.f);
+  for (int64_t pos = 0; pos < P; ++pos) {
+    const float *W1 = d->W1_host + pos * K * H;   // [n_input][n_hidden], right-multiply layout
+    for (int64_t j = 0; j < H; ++j) {
+      float *row = host.data() + (32 * pos + j) * h->kpad;
+      for (int64_t k = 0; k < K; ++k) row[k] = W1[k * H + j];
+      host[h->off_bias + 32 * pos + j] = d->b1_host[pos * H + j];
+      host[h->off_hw + pos * 64 + 2 * j + 0] = d->Wout_host[(pos * H + j) * 2 + 0];
+      host[h->off_hw + pos * 64 + 2 * j + 1] = d->Wout_host[(pos * H + j) * 2 + 1];
+    }
+    host[h->off_hb + 2 * pos + 0] = d->bout_host[2 * pos + 0];
+    host[h->off_hb + 2 * pos + 1] = d->bout_host[2 * pos + 1];
+  }
+  h->dev = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&h->dev), host.size() * sizeof(float)) != hipSuccess) {
+    delete h;
+    return NNV_ERR_OUT_OF_MEMORY;
+  }
+  if (hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(h->dev);
+    delete h;
+    return NNV_ERR_HIP;
+  }
+  *out = h;
+  return NNV_OK;
+}
+
+int32_t nnv_bitwise_free(nnv_bitwise_handle *h) {
+  if (!h) return NNV_OK;
+  const hipError_t e = hipFree(h->dev);
+  delete h;
+  return e == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+}
+
+int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, int64_t n_rows,
+                               uint8_t *bits_dev, float *act_dev, const uint8_t *labels_dev,
+                               uint64_t *errors_dev, void *stream) {
+  if (!h || n_rows < 0) return NNV_ERR_INVALID_ARGUMENT;
+  if (n_rows == 0) return NNV_OK;
+  if (!x_dev || !bits_dev) return NNV_ERR_INVALID_ARGUMENT;
+  if (errors_dev && !labels_dev) return NNV_ERR_INVALID_ARGUMENT;
+  if (reinterpret_cast<uintptr_t>(x_dev) % 8 != 0) return NNV_ERR_INVALID_ARGUMENT;
+  {
+    const nnv_status dv = nnv::check_current_device(h->device);
+    if (dv != NNV_OK) return dv;
+  }
+  nnv::DenseParams p{};
+  p.A = x_dev;
+  p.a_row_stride = h->n_input;
+  p.n_rows = n_rows;
+  p.K = h->n_input;
+  p.Kpad = h->kpad;
+  p.Wt = h->dev;
+  p.bias = h->dev + h->off_bias;
+  p.C = nullptr;
+  p.ldc = 0;
+  p.bn = h->bn;
+  p.nblk_m = h->mpad / h->bn;
+  p.nblk_rows = (n_rows + nnv::kDenseBM - 1) / nnv::kDenseBM;
+  p.act = 2;
+  p.n_pos = h->n_pos;
+  p.head_w = h->dev + h->off_hw;
+  p.head_b = h->dev + h->off_hb;
+  p.bits = bits_dev;
+  p.head_act = act_dev;
+  p.labels = labels_dev;
+  p.errors = reinterpret_cast<unsigned long long *>(errors_dev);
+  return nnv::bitwise_launch(p, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

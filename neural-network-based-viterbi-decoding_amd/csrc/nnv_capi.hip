@@ -291,6 +291,7 @@ int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision, nnv_mlp_h
   h->num_cus = prop.multiProcessorCount;
   h->lds_limit = kLdsLimitBytes;
   h->wpack_dev = nullptr;
+  h->host_ctx = nullptr;
   if (hipMalloc(reinterpret_cast<void **>(&h->wpack_dev), packed.size() * sizeof(float)) != hipSuccess) {
     delete h;
     return NNV_ERR_OUT_OF_MEMORY;
@@ -301,8 +302,13 @@ int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision, nnv_mlp_h
     return NNV_ERR_HIP;
   }
   h->threads = nnv::decode_pick_threads(s);
-  h->vgprs = nnv::decode_kernel_vgprs(s, h->threads);
   const nnv_status prep = nnv::decode_prepare(s, h->num_cus, h->lds_limit, h->threads, dev);
+  {
+    LaunchPlan lp;
+    const bool lean = nnv::decode_plan(s, 1 << 20, h->num_cus, h->lds_limit, h->threads, &lp) == NNV_OK &&
+                      lp.lean_ok && s.streams == 0 && s.n_classes % 32 == 0;
+    h->vgprs = nnv::decode_kernel_vgprs(s, h->threads, lean);
+  }
   if (prep != NNV_OK) {
     (void)hipFree(h->wpack_dev);
     delete h;
@@ -314,6 +320,7 @@ int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision, nnv_mlp_h
 
 int32_t nnv_mlp_free(nnv_mlp_handle *h) {
   if (!h) return NNV_OK;
+  nnv::host_path_release(h);
   const hipError_t e = hipFree(h->wpack_dev);
   delete h;
   return e == hipSuccess ? NNV_OK : NNV_ERR_HIP;
@@ -431,7 +438,7 @@ int32_t nnv_mlp_launch_info(const nnv_mlp_handle *h, int64_t n_rows, int32_t *in
   if (st != NNV_OK) return st;
   info_host[0] = plan.threads;
   info_host[1] = plan.blocks;
-  info_host[2] = plan.lds_bytes;
+  info_host[2] = (plan.lean_ok && h->shape.streams == 0 && h->shape.n_classes % 32 == 0) ? plan.lds_bytes_lean : plan.lds_bytes;
   info_host[3] = h->vgprs;
   info_host[4] = plan.out_in_lds;
   info_host[5] = nnv::kRowsPerTile;

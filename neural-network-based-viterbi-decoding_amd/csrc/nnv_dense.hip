@@ -43,7 +43,11 @@ __device__ __forceinline__ float dense_tanh_f32(float z) {
 // 32 x 32, BK = 32 only) for NARROW layers such as the bit-wise decoder's 1036 -> 30: those are
 // HBM-shaped (4 KB of row in for 62 kFLOP), and padding 30 outputs to a 128-wide tile made them
 // MFMA-bound at 0.21 of the HBM roofline.
-template <bool GATHER, int kBK, int ACT, int BN>
+// HEAD (bit-wise decoder bank, src/fnn_viterbi_bitwise.py:388-397,504-505): the output columns are
+// P independent networks' hidden layers, 32 columns per bit position (30 used), and the epilogue
+// finishes each network in place -- relu(h . Wout + bout) -> argmax over its 2 outputs -- so that the
+// [rows, 32 P] hidden matrix never goes to HBM; one decided bit per (position, row) leaves instead.
+template <bool GATHER, int kBK, int ACT, int BN, bool HEAD = false>
 __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
   static_assert(BN == 128 || (BN == 32 && kBK == 32), "tile shapes");
   constexpr int kBN = BN;                   // shadows the namespace constant inside this kernel
@@ -201,6 +205,49 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
       }
     }
     __syncthreads();
+    if constexpr (HEAD) {
+      // one (row, position) per thread: 64 staged rows x 4 positions (BN 128) or 128 x 1 (BN 32);
+      // a wave holds ONE position (weights through scalar loads), its lanes consecutive rows
+      constexpr int kItems = kStageRows * (kBN / 32);
+      if (tid < kItems) {
+        const int lrow = tid % kStageRows;
+        const int lpos = __builtin_amdgcn_readfirstlane(tid / kStageRows);
+        const int64_t pos = static_cast<int64_t>(col_blk) * (kBN / 32) + lpos;
+        const int64_t row = row0 + (lrow >> 5) * 32 * WT + 32 * a + (lrow & 31);
+        if (pos < p.n_pos) {
+          const float *hw = p.head_w + pos * 64;   // [32 hidden][2 outputs], zero rows beyond n_hidden
+          const float *hv = stage + lrow * kOutStride + 32 * lpos;
+          float s0 = 0.f, s1 = 0.f;                // op order of the reference: matmul, then add, then relu
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const f32x4 h4 = *reinterpret_cast<const f32x4 *>(hv + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s0 = __builtin_fmaf(h4[e], hw[2 * (4 * q + e)], s0);
+              s1 = __builtin_fmaf(h4[e], hw[2 * (4 * q + e) + 1], s1);
+            }
+          }
+          float v0 = s0 + p.head_b[2 * pos], v1 = s1 + p.head_b[2 * pos + 1];
+          v0 = v0 > 0.f ? v0 : 0.f;                // ReLU on the logits too (src/fnn_viterbi_bitwise.py:397)
+          v1 = v1 > 0.f ? v1 : 0.f;
+          const unsigned bit = v1 > v0 ? 1u : 0u;  // tf.argmax over 2 outputs, first maximum on ties
+          const bool live = row < p.n_rows;
+          if (live) {
+            p.bits[pos * p.n_rows + row] = static_cast<uint8_t>(bit);
+            if (p.head_act) {
+              const f32x2 o = {v0, v1};
+              *reinterpret_cast<f32x2 *>(p.head_act + (pos * p.n_rows + row) * 2) = o;
+            }
+          }
+          if (p.errors) {                          // needs labels
+            const bool wrong = live && p.labels[pos * p.n_rows + row] != bit;
+            const unsigned long long m = __ballot(wrong);
+            if (lane == 0 && m) atomicAdd(p.errors + pos, static_cast<unsigned long long>(__popcll(m)));
+          }
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int it = 0; it < (kStageRows * kChunksPerRow) / 256; ++it) {
       const int chunk = tid + 256 * it;
@@ -276,6 +323,18 @@ nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream) {
     NNV_DENSE_LAUNCH(false, 32, 128);
   }
 #undef NNV_DENSE_LAUNCH
+  return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+}
+
+// The bit-wise decoder bank: rows gathered from [n_rows][K] (any even K), ReLU, fused per-position head.
+nnv_status bitwise_launch(const DenseParams &p, hipStream_t stream) {
+  const int64_t blocks = (p.nblk_rows + 7) / 8 * 8 * p.nblk_m;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return NNV_ERR_INVALID_ARGUMENT;
+  if (p.bn != 128 && p.bn != 32) return NNV_ERR_INVALID_ARGUMENT;
+  if (!p.bits || !p.head_w || !p.head_b || (p.errors && !p.labels)) return NNV_ERR_INVALID_ARGUMENT;
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  if (p.bn == 128) hipLaunchKernelGGL((dense_tanh_kernel<true, 32, 2, 128, true>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((dense_tanh_kernel<true, 32, 2, 32, true>), grid, block, 0, stream, p);
   return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 

@@ -142,6 +142,8 @@ struct LaunchPlan {
   int32_t threads;
   int32_t blocks;
   int32_t lds_bytes;
+  int32_t lds_bytes_lean;  // of the lean variant (adds its per-thread argmax slots)
+  int32_t lean_ok;         // the lean variant fits the LDS for this network
   int32_t out_in_lds;
   int32_t out_lds_tiles;
 };
@@ -162,7 +164,7 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
 nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
                          const LaunchPlan &plan, bool write_act, int device,
                          hipStream_t stream);
-int decode_kernel_vgprs(const PackedShape &s, int threads);
+int decode_kernel_vgprs(const PackedShape &s, int threads, bool lean);
 nnv_status decode_prepare(const PackedShape &s, int num_cus, int lds_limit, int threads, int device);
 
 // nnv_dense.hip: layer-at-a-time path for wide networks
@@ -181,6 +183,14 @@ struct DenseParams {
   int64_t nblk_rows;     // ceil(n_rows / 128)
   int32_t act;           // 1 tanh, 2 relu
   int32_t bn;            // output columns per block: 128, or 32 for narrow layers
+  // fused per-position head (bitwise_launch only): column block c holds positions (bn/32) c ..
+  int64_t n_pos;               // bit positions (networks) in the bank
+  const float *head_w;         // [n_pos][32][2] fp32, rows >= n_hidden zero
+  const float *head_b;         // [n_pos][2]
+  uint8_t *bits;               // [n_pos][n_rows] decided bit
+  float *head_act;             // nullable [n_pos][n_rows][2] ReLU'd outputs (parity)
+  const uint8_t *labels;       // nullable [n_pos][n_rows] true bit
+  unsigned long long *errors;  // nullable [n_pos] wrong decisions, ACCUMULATED (needs labels)
 };
 struct HeadParams {
   const float *A;        // [n_rows][lda]
@@ -229,6 +239,7 @@ struct HeadF16Params {
 nnv_status dense_f16x3_launch(const DenseF16Params &p, bool gather, hipStream_t stream);
 nnv_status head_f16x3_launch(const HeadF16Params &p, hipStream_t stream);
 nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream);
+nnv_status bitwise_launch(const DenseParams &p, hipStream_t stream);
 nnv_status head_launch(const HeadParams &p, hipStream_t stream);
 
 // nnv_generator.hip
@@ -237,6 +248,11 @@ nnv_status generate_launch(int32_t code, int32_t tile_bits, int64_t n_rows,
                            const float *sigma, int32_t n_sigma, uint64_t seed,
                            float *x, int32_t *labels, hipStream_t stream);
 
+}  // namespace nnv
+
+namespace nnv {
+struct HostPathCtx;                           // nnv_host_path.hip: persistent pinned staging ring
+void host_path_release(nnv_mlp_handle *h);    // frees it (nnv_mlp_free)
 }  // namespace nnv
 
 struct nnv_mlp_handle {
@@ -248,5 +264,6 @@ struct nnv_mlp_handle {
   int num_cus;
   int lds_limit;
   int threads;  // workgroup size of the decode kernels, picked at prepack
-  int vgprs;    // of the decode instantiation (introspection)
+  int vgprs;    // of the decode instantiation the benchmark call shape uses (lean if eligible)
+  nnv::HostPathCtx *host_ctx;  // created by the first nnv_mlp_decode_host_f32 call on this handle
 };

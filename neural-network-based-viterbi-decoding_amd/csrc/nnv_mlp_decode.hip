@@ -39,6 +39,9 @@
 #ifndef NNV_DEFER_ARGMAX
 #define NNV_DEFER_ARGMAX 1
 #endif
+#ifndef NNV_KEEP_LDS
+#define NNV_KEEP_LDS 1
+#endif
 
 namespace nnv {
 
@@ -205,6 +208,9 @@ __device__ __forceinline__ void act16(f32x16 &acc) {
 // apart here; that is far inside the 1e-5 near-tie rule of DESIGN.md.)
 constexpr float kTanhSat = 9.011f;
 constexpr bool kDeferArgmax = NNV_DEFER_ARGMAX != 0;
+// Lean variant: the running winner's 16 raw accumulators are parked in a per-lane LDS slot by
+// exec-masked ds_write_b128 (no VALU) instead of 16 v_cndmask per class tile; 64 bytes per thread.
+constexpr bool kKeepLds = kDeferArgmax && NNV_KEEP_LDS != 0;
 
 template <int G1, bool VEC_ONLY>
 __device__ __forceinline__ void load_x(const DecodeParams &p, int64_t tile,
@@ -442,6 +448,9 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     // class tile (51 ops x 8 tiles; -DNNV_DEFER_ARGMAX=0 restores that for A/B builds).
     f32x16 keep;
     int btile = 0;
+    constexpr bool KEEP_LDS = LEAN && kKeepLds;
+    // [wave][q][lane][4 floats]: consecutive lanes write consecutive 16-byte pieces (conflict free)
+    float *const keep_slot = reinterpret_cast<float *>(bin_ctr + kMaxBins * 4) + (threadIdx.x >> 6) * 1024 + lane * 4;
     auto scan_first = [&](const f32x16 &acc, float m) -> unsigned {
       unsigned t = 16u;
 #pragma unroll
@@ -455,7 +464,16 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       m = __builtin_amdgcn_fmed3f(m, -kTanhSat, kTanhSat);
       const bool c = m > best;
       best = c ? m : best;
-      if constexpr (kDeferArgmax) {
+      if constexpr (KEEP_LDS) {
+        btile = c ? mt : btile;
+        if (c) {  // exec-masked LDS stores: the LDS port, not the vector ALU the fp32 MFMA occupies
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *reinterpret_cast<f32x4 *>(keep_slot + q * 256) = v;
+          }
+        }
+      } else if constexpr (kDeferArgmax) {
         btile = c ? mt : btile;
 #pragma unroll
         for (int r = 0; r < 16; ++r) keep[r] = c ? acc[r] : keep[r];
@@ -521,6 +539,14 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         }
       }
       argmax_tile(acc, mt);
+    }
+    if constexpr (KEEP_LDS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(keep_slot + q * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep[4 * q + e] = v[e];
+      }
     }
     if constexpr (kDeferArgmax) {
       const unsigned t = scan_first(keep, best);
@@ -689,8 +715,8 @@ nnv_status decode_supported(const PackedShape &s) {
 
 int decode_pick_threads(const PackedShape &s) { return pick_threads_impl(s); }
 
-int decode_kernel_vgprs(const PackedShape &s, int threads) {
-  const KernelEntry *k = find_kernel(s, threads, false);
+int decode_kernel_vgprs(const PackedShape &s, int threads, bool lean) {
+  const KernelEntry *k = find_kernel(s, threads, false, lean);
   if (!k) return 0;
   hipFuncAttributes attr;
   if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) return 0;
@@ -710,6 +736,9 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
   plan->out_in_lds = fit == s.mt_out ? 1 : 0;
   plan->lds_bytes = static_cast<int32_t>(base_floats * 4 + fit * per_tile_bytes) + kLdsTailBytes;  // + work counter, bin counters
   plan->threads = threads;
+  // the lean variant parks the running argmax winner's accumulators in LDS: 64 bytes per thread
+  plan->lds_bytes_lean = plan->lds_bytes + (kKeepLds ? threads * 64 : 0);
+  plan->lean_ok = (plan->out_in_lds && plan->lds_bytes_lean <= lds_limit) ? 1 : 0;
   // Persistent: one workgroup per CU.  Small batches are spread over as many CUs as they have
   // tiles (one busy wave per CU, the others find no work and leave) rather than packed 16 tiles to
   // a CU: BASELINE configs[0] (2,000 rows) 107 -> 39 us per launch, 20,000 rows 110 -> 63 us.
@@ -751,7 +780,8 @@ nnv_status decode_prepare(const PackedShape &s, int num_cus, int lds_limit, int 
   for (const int which : {0, 1, 2}) {  // decode, debug forward, lean decode
     const KernelEntry *k = find_kernel(s, which == 1 ? 512 : plan.threads, which == 1, which == 2);
     if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
-    const nnv_status e = ensure_lds_optin(device, k, plan.lds_bytes);
+    if (which == 2 && !plan.lean_ok) continue;
+    const nnv_status e = ensure_lds_optin(device, k, which == 2 ? plan.lds_bytes_lean : plan.lds_bytes);
     if (e != NNV_OK) return e;
   }
   return NNV_OK;
@@ -762,11 +792,13 @@ nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
                          hipStream_t stream) {
   const int nt = write_act ? 512 : plan.threads;
   static const bool no_lean = getenv("NNV_NO_LEAN") != nullptr;  // A/B runs only
-  const bool lean = !no_lean && !write_act && p.xvec && p.n_bins == 1 && !p.bits && !p.cls64 && p.n_classes % 32 == 0;
+  const bool lean = !no_lean && plan.lean_ok && s.streams == 0 && !write_act && p.xvec && p.n_bins == 1 && !p.bits &&
+                    !p.cls64 && p.n_classes % 32 == 0;
   const KernelEntry *k = find_kernel(s, nt, write_act, lean);
   if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
+  const int lds_bytes = lean ? plan.lds_bytes_lean : plan.lds_bytes;
   {
-    const nnv_status e = ensure_lds_optin(device, k, plan.lds_bytes);
+    const nnv_status e = ensure_lds_optin(device, k, lds_bytes);
     if (e != NNV_OK) return e;
   }
   int blocks = plan.blocks;
@@ -774,7 +806,7 @@ nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
     const int64_t b = (p.n_tiles + 7) / 8;
     blocks = static_cast<int>(b < plan.blocks ? (b < 1 ? 1 : b) : plan.blocks);
   }
-  hipLaunchKernelGGL(k->fn, dim3(blocks), dim3(nt), plan.lds_bytes, stream, p);
+  hipLaunchKernelGGL(k->fn, dim3(blocks), dim3(nt), lds_bytes, stream, p);
   return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 

@@ -252,7 +252,7 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev, int64_
         if (st != NNV_OK) return st;
         break;
       }
-      nnv::DenseParams dp;
+      nnv::DenseParams dp{};
       dp.A = in;
       dp.a_row_stride = in_stride;
       dp.n_rows = rows;

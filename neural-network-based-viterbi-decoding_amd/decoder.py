@@ -190,19 +190,15 @@ class PackedMLP:
         return {"cls32": cls32, "counters": counters}
 
     def decode_host(self, x_host: np.ndarray, labels_host: Optional[np.ndarray] = None,
-                    tile_bits: Optional[int] = None, chunk_rows: int = 1 << 21,
-                    register_host: Optional[bool] = None):
+                    tile_bits: Optional[int] = None, chunk_rows: int = 1 << 21, threads: int = 0):
         """The reference's call shape: a HOST ``test_set`` in, host predictions out
-        (``predictions_tensor.eval(feed_dict={x: test_set})``, src/fnn_viterbi.py:610).
+        (``predictions_tensor.eval(feed_dict={x: test_set})``, src/fnn_viterbi.py:610), as one
+        synchronous C-ABI call (``nnv_mlp_decode_host_f32``).
 
-        The rows are streamed through the GPU in chunks with double-buffered device staging so
-        that the PCIe transfers overlap the kernel.  ``register_host``:
-          * None (default): plain copies from the caller's pageable arrays; the runtime stages them
-            through its own pinned buffers at link speed (measured 56 GB/s), the host thread is
-            blocked in chunk i+1's copy while the GPU decodes chunk i;
-          * True: the caller's arrays are page-locked in place (hipHostRegister: ~20 ms per GB, worth
-            it only for arrays decoded repeatedly) and three HIP streams run H2D, decode and D2H;
-          * False: the same three streams fed through two pinned staging buffers.
+        The rows are streamed through a ring of page-locked staging slots owned by the packed
+        network (allocated on the first call, reused afterwards): pageable -> pinned copies on
+        ``threads`` host threads (0 = the CPUs this process may use, at most 16), H2D DMA, the fused
+        decode launch and the D2H of the classes overlap on different chunks of ``chunk_rows`` rows.
         Returns ``(cls int64 [N], counters int64[4] | None)``."""
         x_host = np.ascontiguousarray(x_host, dtype=np.float32)
         if x_host.ndim != 2 or x_host.shape[1] != self.n_input:
@@ -214,133 +210,17 @@ class PackedMLP:
             lab_host = np.ascontiguousarray(labels_host, dtype=np.int32)
             if lab_host.shape != (n,):
                 raise ValueError("labels must be [N]")
-        out32 = np.empty(n, dtype=np.int32)
-        counters = torch.zeros(4, dtype=torch.int64, device=self.device) if lab_host is not None else None
-        if n == 0:
-            return out32.astype(np.int64), (None if counters is None else counters.cpu().numpy())
-        m = int(min(max(1, chunk_rows), n))
-        dev = self.device
-        if register_host is None:
-            with torch.cuda.device(dev):
-                xs, outs = torch.from_numpy(x_host), torch.from_numpy(out32)
-                ls = torch.from_numpy(lab_host) if lab_host is not None else None
-                xd = [torch.empty((m, self.n_input), dtype=torch.float32, device=dev) for _ in range(2)]
-                cd = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(2)]
-                ld = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(2)] if ls is not None else None
-                s_cmp = torch.cuda.current_stream(dev)
-                s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-                pending = None                      # (event, buffer, lo, hi) of the chunk being decoded
-
-                def drain(p):                       # its classes back to the host, beside the next decode
-                    ev, k, plo, phi = p
-                    with torch.cuda.stream(s_out):
-                        s_out.wait_event(ev)
-                        outs[plo:phi].copy_(cd[k][: phi - plo])       # pageable: returns when done
-
-                for i in range((n + m - 1) // m):
-                    k = i & 1
-                    lo, hi = i * m, min(n, (i + 1) * m)
-                    cnt = hi - lo
-                    with torch.cuda.stream(s_in):   # pageable copies block the host, not the decode stream:
-                        xd[k][:cnt].copy_(xs[lo:hi])                  # chunk i-1 is being decoded meanwhile
-                        if ld is not None:
-                            ld[k][:cnt].copy_(ls[lo:hi])
-                    st = self._lib.nnv_mlp_decode_f32(
-                        self._handle, _ptr(xd[k]), cnt, b, _ptr(ld[k]) if ld is not None else None,
-                        _ptr(cd[k]), None, None, _ptr(counters), _stream_ptr(dev))
-                    _cabi.check(st, "nnv_mlp_decode_f32")
-                    ev = s_cmp.record_event()
-                    if pending is not None:
-                        drain(pending)              # buffer k ^ 1 is free again before chunk i+1 is copied
-                    pending = (ev, k, lo, hi)
-                drain(pending)
-                torch.cuda.synchronize(dev)
-            return out32.astype(np.int64), (None if counters is None else counters.cpu().numpy())
-        rt = torch.cuda.cudart()
-        registered = []
-
-        def _register(a: np.ndarray) -> bool:
-            try:
-                if int(rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)) == 0:
-                    registered.append(a)
-                    return True
-            except Exception:
-                pass
-            return False
-
-        direct = register_host and _register(x_host) and _register(out32) and \
-            (lab_host is None or _register(lab_host))
-        try:
-            with torch.cuda.device(dev):
-                s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-                s_cmp = torch.cuda.current_stream(dev)
-                xd = [torch.empty((m, self.n_input), dtype=torch.float32, device=dev) for _ in range(2)]
-                cd = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(2)]
-                ld = [torch.empty(m, dtype=torch.int32, device=dev) for _ in range(2)] if lab_host is not None else None
-                if direct:
-                    xs, outs = torch.from_numpy(x_host), torch.from_numpy(out32)
-                    ls = torch.from_numpy(lab_host) if lab_host is not None else None
-                else:
-                    px = [torch.empty((m, self.n_input), dtype=torch.float32).pin_memory() for _ in range(2)]
-                    pc = [torch.empty(m, dtype=torch.int32).pin_memory() for _ in range(2)]
-                    pl = [torch.empty(m, dtype=torch.int32).pin_memory() for _ in range(2)] if lab_host is not None else None
-                ev_in = [None, None]
-                ev_cmp = [None, None]
-                ev_out = [None, None]
-                pending = [None, None]          # (lo, hi) of the chunk whose result sits in pc[k]
-                n_chunks = (n + m - 1) // m
-                for i in range(n_chunks):
-                    k = i & 1
-                    lo, hi = i * m, min(n, (i + 1) * m)
-                    cnt = hi - lo
-                    if not direct and pending[k] is not None:       # result of chunk i-2 back on the host?
-                        ev_out[k].synchronize()
-                        plo, phi = pending[k]
-                        out32[plo:phi] = pc[k][: phi - plo].numpy()
-                        pending[k] = None
-                    with torch.cuda.stream(s_in):
-                        if ev_cmp[k] is not None:
-                            s_in.wait_event(ev_cmp[k])               # device buffer k is free again
-                        if direct:
-                            xd[k][:cnt].copy_(xs[lo:hi], non_blocking=True)
-                            if ld is not None:
-                                ld[k][:cnt].copy_(ls[lo:hi], non_blocking=True)
-                        else:
-                            px[k][:cnt].copy_(torch.from_numpy(x_host[lo:hi]))
-                            xd[k][:cnt].copy_(px[k][:cnt], non_blocking=True)
-                            if ld is not None:
-                                pl[k][:cnt].copy_(torch.from_numpy(lab_host[lo:hi]))
-                                ld[k][:cnt].copy_(pl[k][:cnt], non_blocking=True)
-                        ev_in[k] = s_in.record_event()
-                    s_cmp.wait_event(ev_in[k])
-                    if ev_out[k] is not None:
-                        s_cmp.wait_event(ev_out[k])                  # cls buffer k has been drained
-                    st = self._lib.nnv_mlp_decode_f32(
-                        self._handle, _ptr(xd[k]), cnt, b, _ptr(ld[k]) if ld is not None else None,
-                        _ptr(cd[k]), None, None, _ptr(counters), _stream_ptr(dev))
-                    _cabi.check(st, "nnv_mlp_decode_f32")
-                    ev_cmp[k] = s_cmp.record_event()
-                    with torch.cuda.stream(s_out):
-                        s_out.wait_event(ev_cmp[k])
-                        if direct:
-                            outs[lo:hi].copy_(cd[k][:cnt], non_blocking=True)
-                        else:
-                            pc[k][:cnt].copy_(cd[k][:cnt], non_blocking=True)
-                            pending[k] = (lo, hi)
-                        ev_out[k] = s_out.record_event()
-                torch.cuda.synchronize(dev)
-                if not direct:
-                    for k in range(2):
-                        if pending[k] is not None:
-                            plo, phi = pending[k]
-                            out32[plo:phi] = pc[k][: phi - plo].numpy()
-        finally:
-            for a in registered:
-                try:
-                    rt.cudaHostUnregister(a.ctypes.data)
-                except Exception:
-                    pass
-        return out32.astype(np.int64), (None if counters is None else counters.cpu().numpy())
+        cls64 = np.empty(n, dtype=np.int64)
+        counters = np.zeros(4, dtype=np.uint64) if lab_host is not None else None
+        with torch.cuda.device(self.device):
+            st = self._lib.nnv_mlp_decode_host_f32(
+                self._handle, ctypes.c_void_p(x_host.ctypes.data), n, b,
+                None if lab_host is None else ctypes.c_void_p(lab_host.ctypes.data), None,
+                ctypes.c_void_p(cls64.ctypes.data),
+                None if counters is None else ctypes.c_void_p(counters.ctypes.data),
+                int(max(1, chunk_rows)), int(threads))
+        _cabi.check(st, "nnv_mlp_decode_host_f32")
+        return cls64, (None if counters is None else counters.astype(np.int64))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """The tanh'd output layer [N, n_classes] (debug / parity; slow)."""
@@ -472,6 +352,79 @@ class WideMLP:
         if n < 0 or n > most:
             raise ValueError(f"the stream holds at most {most} windows")
         return self._run(stream, n, stride, want_act, want_cls64)
+
+
+class BitwiseBank:
+    """P bit-wise decoder networks ``n_input -> n_hidden (ReLU) -> 2 (ReLU) -> argmax`` evaluated on
+    the same received rows in ONE fused launch (C ABI ``nnv_bitwise_*``).
+
+    The reference trains one such network per ``bit_position`` and evaluates them one at a time
+    (src/fnn_viterbi_bitwise.py:326-399,503-505).  ``models`` is a sequence of
+    ``(W1 [n_input, n_hidden], b1 [n_hidden], Wout [n_hidden, 2], bout [2])``, one per position."""
+
+    def __init__(self, models: Sequence, device=None):
+        _require_cuda()
+        self._lib = _cabi.load_library()
+        self.device = torch.device("cuda", torch.cuda.current_device()
+                                   if device is None else torch.device(device).index or 0)
+        if len(models) < 1:
+            raise ValueError("need at least one network")
+        W1 = np.ascontiguousarray(np.stack([_as_host_f32(m[0]) for m in models]))
+        b1 = np.ascontiguousarray(np.stack([_as_host_f32(m[1]).reshape(-1) for m in models]))
+        Wo = np.ascontiguousarray(np.stack([_as_host_f32(m[2]) for m in models]))
+        bo = np.ascontiguousarray(np.stack([_as_host_f32(m[3]).reshape(-1) for m in models]))
+        P, K, H = W1.shape
+        if b1.shape != (P, H) or Wo.shape != (P, H, 2) or bo.shape != (P, 2):
+            raise ValueError("every network must be (W1 [K, H], b1 [H], Wout [H, 2], bout [2]) with one K, H")
+        self.n_positions, self.n_input, self.n_hidden = P, K, H
+        desc = _cabi.BitwiseDesc()
+        desc.n_input, desc.n_hidden, desc.n_positions = K, H, P
+        desc.W1_host, desc.b1_host = W1.ctypes.data, b1.ctypes.data
+        desc.Wout_host, desc.bout_host = Wo.ctypes.data, bo.ctypes.data
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _cabi.check(self._lib.nnv_bitwise_prepack(ctypes.byref(desc), ctypes.byref(handle)),
+                        "nnv_bitwise_prepack")
+        self._handle = handle
+
+    def close(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            self._lib.nnv_bitwise_free(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode(self, x: torch.Tensor, labels: Optional[torch.Tensor] = None, want_act: bool = False,
+               errors: Optional[torch.Tensor] = None):
+        """``x`` float32 CUDA [N, n_input] -> ``bits`` uint8 [P, N] (row p = the prediction vector of
+        network p).  ``labels`` uint8 [P, N] (true bits) adds per-position wrong-decision counts to
+        ``errors`` int64 [P] (created zeroed if None); ``want_act`` also returns the ReLU'd outputs
+        float32 [P, N, 2] (parity)."""
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+                and x.shape[1] == self.n_input and x.is_contiguous() and x.device == self.device):
+            raise ValueError(f"x must be a contiguous float32 tensor [N, {self.n_input}] on {self.device}")
+        n, P = x.shape[0], self.n_positions
+        bits = torch.empty((P, n), dtype=torch.uint8, device=self.device)
+        act = torch.empty((P, n, 2), dtype=torch.float32, device=self.device) if want_act else None
+        if labels is not None:
+            if not (labels.is_cuda and labels.dtype == torch.uint8 and tuple(labels.shape) == (P, n)
+                    and labels.is_contiguous()):
+                raise ValueError("labels must be a contiguous uint8 CUDA tensor [P, N]")
+            if errors is None:
+                errors = torch.zeros(P, dtype=torch.int64, device=self.device)
+        elif errors is not None:
+            raise ValueError("errors need labels")
+        if errors is not None and (errors.dtype != torch.int64 or tuple(errors.shape) != (P,)):
+            raise ValueError("errors must be int64 [P]")
+        with torch.cuda.device(self.device):
+            st = self._lib.nnv_bitwise_decode_f32(self._handle, _ptr(x), n, _ptr(bits), _ptr(act),
+                                                  _ptr(labels), _ptr(errors), _stream_ptr(self.device))
+        _cabi.check(st, "nnv_bitwise_decode_f32")
+        return {"bits": bits, "act": act, "errors": errors}
 
 
 class Seq2SeqLSTM:

@@ -174,6 +174,33 @@ def predict(test_encoded: np.ndarray, weights: Dict, biases: Dict) -> np.ndarray
     return _run(test_encoded, weights, biases, want_cls64=True)["cls64"].cpu().numpy()
 
 
+def predict_all_positions(test_encoded: np.ndarray, models, test_info: Optional[np.ndarray] = None,
+                          bit_positions=None):
+    """Every trained bit position of a block in ONE fused launch (``decoder.BitwiseBank``).
+
+    The reference evaluates one network per run (``bit_position``, src/fnn_viterbi_bitwise.py:
+    503-505); decoding a block that way costs one pass over ``test_encoded`` per position.
+    ``models``: one ``(weights, biases)`` pair per position, as ``train_and_evaluate`` leaves them.
+    Returns ``predictions`` int64 [N, P] (column p = what ``predict`` returns for network p) and,
+    with ``test_info`` [N, L] and ``bit_positions`` (default 0..P-1), the error rate per position."""
+    import torch
+    from .decoder import BitwiseBank
+    bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models])
+    try:
+        xd = torch.from_numpy(np.ascontiguousarray(np.asarray(test_encoded), dtype=np.float32)).cuda()
+        labels = None
+        if test_info is not None:
+            pos = np.arange(len(models)) if bit_positions is None else np.asarray(bit_positions)
+            labels = torch.from_numpy(np.ascontiguousarray(np.asarray(test_info)[:, pos].T.astype(np.uint8))).cuda()
+        r = bank.decode(xd, labels=labels)
+        preds = r["bits"].cpu().numpy().T.astype(np.int64)
+        if labels is None:
+            return preds
+        return preds, r["errors"].cpu().numpy() / max(1, preds.shape[0])
+    finally:
+        bank.close()
+
+
 def save_model(path: str, weights: Dict, biases: Dict) -> str:
     path = path if path.endswith(".npz") else path + ".npz"
     if os.path.dirname(path):

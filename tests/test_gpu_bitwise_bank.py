@@ -1,0 +1,93 @@
+"""The bit-wise decoder BANK (C ABI nnv_bitwise_*, decoder.BitwiseBank): P networks
+2(6+L) -> 30 (ReLU) -> 2 (ReLU) -> argmax, one per information-bit position
+(src/fnn_viterbi_bitwise.py:326-399,503-505), in one fused launch - against the oracle PER POSITION
+(numpy float64 arbiter + the C fp32 restatement, activation="relu"), and against the package's own
+one-position-per-launch path.  Parity of the forward arithmetic stays unpinned (no TensorFlow)."""
+import numpy as np
+import pytest
+import torch
+
+import nnviterbi_amd  # noqa: F401
+from nnviterbi_amd import fnn_viterbi_bitwise as bw
+from nnviterbi_amd.decoder import BitwiseBank
+from oracle import fnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(cfg, n_pos, seed, bout=None):
+    models = []
+    for p in range(n_pos):
+        w, b = bw.initialize_weights(cfg, rng=np.random.RandomState(seed + p))
+        b["b1"] = (np.random.RandomState(1000 + seed + p).randn(cfg.n_hidden_1) * 0.05).astype(np.float32)
+        b["out"] = np.array([-0.3, 0.1] if bout is None else bout, dtype=np.float32)
+        models.append((w, b))
+    return models
+
+
+def _check_position(bits, act, x, w, b):
+    Ws, bs = bw.active_layers(w, b)
+    c64, _, o64 = O.decode(x, Ws, bs, 1, np.float64, activation="relu")
+    assert np.abs(act - o64).max() < 2e-5 * max(1.0, np.abs(o64).max())
+    bad = bits != c64
+    assert not bad.any() or O.top2_margin(o64)[bad].max() < 1e-4
+    ref = O.decode_c(x, Ws, bs, 1, want_bits=False, activation="relu")
+    assert (ref["cls"] != bits).sum() <= max(3, len(bits) // 1000)
+    both_zero = (o64 == 0).all(axis=1)
+    assert (bits[both_zero] == 0).all()                  # ReLU'd ties -> first class (bit 0)
+    return int(bad.sum())
+
+
+@pytest.mark.parametrize("block_length,n_pos,n_rows", [(512, 9, 1500), (24, 24, 777), (24, 1, 300),
+                                                       (24, 4, 128), (25, 6, 129), (40, 3, 1)])
+def test_bank_matches_oracle_per_position(cuda_device, block_length, n_pos, n_rows):
+    cfg = bw.BitwiseDecoderConfig(block_length=block_length, training_size=4, test_size=n_rows, test_snr_index=3)
+    np.random.seed(block_length + n_pos)
+    info, enc = bw.generate_test_data(cfg)
+    models = _models(cfg, n_pos, seed=7)
+    x = enc.astype(np.float32)
+    bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models])
+    labels = torch.from_numpy(np.ascontiguousarray(info[:, :n_pos].T.astype(np.uint8))).cuda()
+    r = bank.decode(torch.from_numpy(x).cuda(), labels=labels, want_act=True)
+    bits, act, errors = r["bits"].cpu().numpy(), r["act"].cpu().numpy(), r["errors"].cpu().numpy()
+    assert bits.shape == (n_pos, n_rows) and act.shape == (n_pos, n_rows, 2)
+    for p, (w, b) in enumerate(models):
+        _check_position(bits[p].astype(np.int64), act[p], x, w, b)
+        assert errors[p] == int((bits[p] != info[:, p]).sum())       # counters: exact integer function of the bits
+    # accumulate: a second launch adds to the same counters
+    r2 = bank.decode(torch.from_numpy(x).cuda(), labels=labels, errors=r["errors"])
+    assert np.array_equal(r2["errors"].cpu().numpy(), 2 * errors)
+    bank.close()
+
+
+def test_bank_equals_the_one_position_per_launch_path(cuda_device):
+    """predict_all_positions (one fused launch) == predict() called per trained network."""
+    cfg = bw.BitwiseDecoderConfig(block_length=64, training_size=4, test_size=5000, test_snr_index=5)
+    np.random.seed(3)
+    info, enc = bw.generate_test_data(cfg)
+    models = _models(cfg, 10, seed=21, bout=[0.05, 0.0])
+    preds, err = bw.predict_all_positions(enc, models, test_info=info)
+    assert preds.shape == (5000, 10) and preds.dtype == np.int64
+    for p, (w, b) in enumerate(models):
+        single = bw.predict(enc, w, b)
+        assert (single != preds[:, p]).sum() <= 2                     # K4 head kernel vs fused epilogue: near-ties only
+        assert err[p] == pytest.approx(np.mean(preds[:, p] != info[:, p]))
+    assert np.array_equal(bw.predict_all_positions(enc, models), preds)
+
+
+def test_bank_argument_validation(cuda_device):
+    cfg = bw.BitwiseDecoderConfig(block_length=24)
+    models = _models(cfg, 2, seed=1)
+    bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models])
+    x = torch.zeros((10, cfg.n_input), device="cuda")
+    assert bank.decode(x[:0])["bits"].shape == (2, 0)                 # empty input: no-op
+    with pytest.raises(ValueError):
+        bank.decode(x[:, :-2].contiguous())
+    with pytest.raises(ValueError):
+        bank.decode(x, errors=torch.zeros(2, dtype=torch.int64, device="cuda"))   # errors need labels
+    with pytest.raises(ValueError):
+        bank.decode(x, labels=torch.zeros((10, 2), dtype=torch.uint8, device="cuda"))  # [P, N], not [N, P]
+    bank.close()
+    with pytest.raises(Exception):
+        BitwiseBank([(np.zeros((60, 40), np.float32), np.zeros(40, np.float32),       # n_hidden > 32
+                      np.zeros((40, 2), np.float32), np.zeros(2, np.float32))])

@@ -176,10 +176,11 @@ def test_misaligned_and_strided_inputs(cuda_device):
     net.close()
 
 
-@pytest.mark.parametrize("register_host", [None, True, False])
-def test_host_array_pipeline_equals_resident_decode(cuda_device, register_host):
-    """The reference's call shape (host test_set in, host predictions out): chunked,
-    three-stream H2D / decode / D2H pipeline, with and without in-place page-locking."""
+@pytest.mark.parametrize("threads", [0, 1, 5])
+def test_host_array_pipeline_equals_resident_decode(cuda_device, threads):
+    """The reference's call shape (host test_set in, host predictions out) through the C ABI's
+    host entry: chunked pinned ring, staging threads, H2D / decode / D2H on three streams.
+    Bit-exact with the resident decode for every chunking, ragged tails and ring wrap-around."""
     dims, b, n = [16, 128, 64, 32, 256], 8, 10_007
     Ws, bs = _net(dims, 11)
     rng = np.random.RandomState(5)
@@ -187,16 +188,44 @@ def test_host_array_pipeline_equals_resident_decode(cuda_device, register_host):
     labels = rng.randint(0, 256, n).astype(np.int32)
     net = PackedMLP(Ws, bs)
     want = _hip_decode(net, x, labels, b)
-    for chunk in (1000, 4096, 1 << 20):
-        cls, counters = net.decode_host(x, labels, b, chunk_rows=chunk, register_host=register_host)
+    for chunk in (1, 37, 1000, 4096, 1 << 20):       # 1 -> one 32-row slot per chunk: 313 trips round the ring
+        cls, counters = net.decode_host(x, labels, b, chunk_rows=chunk, threads=threads)
         assert cls.dtype == np.int64 and np.array_equal(cls, want["cls64"])
         assert np.array_equal(counters, want["counters"])
     cls, counters = net.decode_host(x[:0], None, b)
     assert cls.shape == (0,) and counters is None
-    cls, counters = net.decode_host(x, None, b, chunk_rows=3000, register_host=register_host)
+    cls, counters = net.decode_host(x, None, b, chunk_rows=3000, threads=threads)       # ring re-sized, no labels
     assert counters is None and np.array_equal(cls, want["cls64"])
+    cls, counters = net.decode_host(x[::2], labels[::2], b, chunk_rows=512)             # strided views are compacted
+    assert np.array_equal(cls, want["cls64"][::2])
     with pytest.raises(ValueError):
         net.decode_host(x[:, :8], None, b)
+    net.close()
+
+
+def test_host_entry_of_the_c_abi_directly(cuda_device):
+    """nnv_mlp_decode_host_f32 as a C caller uses it: int32 and int64 class outputs, counters ADDED
+    to, argument errors as status codes."""
+    import ctypes
+    from nnviterbi_amd import _cabi
+    lib = _cabi.load_library()
+    dims, b, n = [14, 128, 64, 32, 128], 7, 5001
+    Ws, bs = _net(dims, 13)
+    rng = np.random.RandomState(8)
+    x = rng.randn(n, 14).astype(np.float32)
+    labels = rng.randint(0, 128, n).astype(np.int32)
+    net = PackedMLP(Ws, bs)
+    want = _hip_decode(net, x, labels, b)
+    c32, c64 = np.empty(n, np.int32), np.empty(n, np.int64)
+    cnt = np.array([5, 6, 7, 8], dtype=np.uint64)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+    st = lib.nnv_mlp_decode_host_f32(net._handle, p(x), n, b, p(labels), p(c32), p(c64), p(cnt), 999, 3)
+    assert st == 0
+    assert np.array_equal(c32, want["cls32"]) and np.array_equal(c64, want["cls64"])
+    assert np.array_equal(cnt.astype(np.int64), want["counters"] + np.array([5, 6, 7, 8]))
+    assert lib.nnv_mlp_decode_host_f32(net._handle, p(x), n, b, None, p(c32), None, p(cnt), 0, 0) == 1  # counters w/o labels
+    assert lib.nnv_mlp_decode_host_f32(net._handle, None, n, b, None, p(c32), None, None, 0, 0) == 1
+    assert lib.nnv_mlp_decode_host_f32(net._handle, p(x), 0, b, None, None, None, None, 0, 0) == 0
     net.close()
 
 
@@ -426,6 +455,59 @@ def test_mixed_snr_sweep_per_bin_counters(cuda_device):
     net.close()
 
 
+# ------------------------------------------------------------------ BASELINE configs[3] at one GPU's FULL share
+@pytest.mark.timeout(900)
+def test_mixed_snr_sweep_full_per_gpu_share(cuda_device):
+    """BASELINE configs[3]: 100 M blocks of block_len 1024 (128 tiles of b = 8) block-sharded over 8
+    GPUs = 12.5 M blocks = 1.6 G rows per GPU, SNR of block i = (i mod 7) dB.  Rank 3's share (it
+    starts mid-sweep and its chunks do not align with blocks) is generated on the device and decoded
+    through distributed.decode_blocks_sharded, and checked by size-independent identities plus an
+    oracle sample cut from the middle of the share."""
+    from nnviterbi_amd import distributed as nd
+    b, rpb, total, world, rank, seed = 8, 128, 100_000_000, 8, 3, 20240607
+    sig = np.array([O.sigma_from_snr_db(d) for d in range(7)], dtype=np.float32)
+    Ws, bs = matched_filter_network(b, "133171")
+    net = PackedMLP(Ws, bs)
+    first_block, n_blocks = nd.block_shard(total, rank, world)
+    assert (first_block, n_blocks) == (37_500_000, 12_500_000)
+    got = nd.decode_blocks_sharded(net, "133171", b, total, rpb, sig, seed, rank=rank, world_size=world,
+                                   chunk_rows=(1 << 26) + 192).cpu().numpy()      # chunks end inside blocks
+    # (1) every row counted exactly once, in the bin of its GLOBAL block index
+    blocks_in_bin = np.array([len(range(first_block + ((k - first_block) % 7), first_block + n_blocks, 7))
+                              for k in range(7)])
+    assert np.array_equal(got[:, 3], blocks_in_bin * rpb) and got[:, 3].sum() == n_blocks * rpb
+    assert np.array_equal(got[:, 2], got[:, 3] * b)
+    assert np.all(got[:, 1] <= got[:, 3]) and np.all(got[:, 0] >= got[:, 1]) and np.all(got[:, 0] <= got[:, 1] * b)
+    # (2) BER falls monotonically over 0..6 dB and sits where the matched filter must put it
+    ber = got[:, 0] / got[:, 2]
+    assert np.all(np.diff(ber) < 0) and 1e-2 < ber[0] < 1e-1 and ber[6] < 1e-3
+    # (3) sub-shares add up: blocks [first, first + 300k) as one piece == the same blocks as 3 "ranks"
+    sub_first, sub_n = first_block * rpb, 300_000
+    x, lab = generate_awgn_blocks("133171", b, sub_n * rpb, sig, seed, first_row=sub_first, rows_per_block=rpb)
+    whole = net.decode_binned(x, lab, 7, rpb, first_row=sub_first, want_cls32=True)
+    parts = torch.zeros((7, 4), dtype=torch.int64, device="cuda")
+    for k in range(3):
+        lo, cnt = nd.block_shard(sub_n, k, 3)
+        net.decode_binned(x[lo * rpb:(lo + cnt) * rpb], lab[lo * rpb:(lo + cnt) * rpb], 7, rpb,
+                          first_row=sub_first + lo * rpb, counters=parts)
+    assert torch.equal(parts, whole["counters"])
+    # (4) oracle sample: 70 blocks (10 per bin) out of the middle of that piece
+    lo = 123_456 * rpb
+    m = 70 * rpb
+    xs, ls = x[lo:lo + m].cpu().numpy(), lab[lo:lo + m].cpu().numpy()
+    ref = O.decode_c(xs, Ws, bs, b, labels=ls, want_bits=False)
+    cls = whole["cls32"][lo:lo + m].cpu().numpy()
+    assert (cls != ref["cls"]).sum() <= 1
+    bins = ((sub_first + lo + np.arange(m)) // rpb) % 7
+    r = net.decode_binned(x[lo:lo + m], lab[lo:lo + m], 7, rpb, first_row=sub_first + lo)
+    want = np.stack([O.error_counters(cls[bins == k], ls[bins == k], b) for k in range(7)])
+    assert np.array_equal(r["counters"].cpu().numpy(), want)
+    # (5) the generator is keyed by the GLOBAL row: the same rows drawn as part of a larger request
+    x2, lab2 = generate_awgn_blocks("133171", b, m, sig, seed, first_row=sub_first + lo, rows_per_block=rpb)
+    assert torch.equal(x2, x[lo:lo + m]) and torch.equal(lab2, lab[lo:lo + m])
+    net.close()
+
+
 # ------------------------------------------------------------------ reference-shaped API on the GPU
 def test_reference_api_predict_and_metrics(cuda_device, golden):
     g, _ = golden
@@ -630,3 +712,40 @@ def test_handle_packed_on_one_gpu_is_refused_on_another(cuda_device):
     assert torch.equal(r0["cls32"].cpu(), r1["cls32"].cpu())
     net0.close()
     net1.close()
+
+
+# ------------------------------------------------------------------ triangulation with the independent CPU implementation
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_hip_against_torch_cpu_and_fp64_on_fixtures_and_trained_net(cuda_device, forward_golden, precision):
+    """Parity of the forward pass is UNPINNED (TensorFlow cannot run here).  The strongest evidence
+    available: PyTorch's CPU kernels (oracle/torch_cpu.py, op order matmul -> add -> tanh of
+    src/fnn_viterbi.py:495-508) are the one independent fp32 implementation importable, and the HIP
+    path must stand to them exactly as our own restatements do: outputs within 1e-5 of the float64
+    chain, classes differing only on rows whose float64 top-2 margin is below 1e-5."""
+    import os
+    from oracle import torch_cpu as T
+    cases = []
+    for name, depth, b in (("b8_l3", 4, 8), ("b7_l3", 4, 7), ("b10_l2", 3, 10), ("b3_l3", 4, 3)):
+        cases.append(([forward_golden[f"{name}_W{i}"] for i in range(depth)],
+                      [forward_golden[f"{name}_b{i}"] for i in range(depth)], forward_golden[f"{name}_x"], b))
+    ck = np.load(os.path.join(os.path.dirname(nnviterbi_amd.__path__[0]), "neural-network-based-viterbi-decoding_amd",
+                              "weights", "fnn_133171_b8_2dB.npz"), allow_pickle=False)
+    xt, _ = awgn_model.generate("133171", 8, 200_000, O.sigma_from_snr_db(2.0), 20240607, rows_per_block=8)
+    cases.append(([ck[k] for k in ("weights_h1", "weights_h2", "weights_h3", "weights_out")],
+                  [ck[k] for k in ("bias_h1", "bias_h2", "bias_h3", "bias_out")], xt.astype(np.float32), 8))
+    for Ws, bs, x, b in cases:
+        net = PackedMLP(Ws, bs, precision=precision)
+        xd = torch.from_numpy(x).cuda()
+        cls = net.decode(xd, tile_bits=b)["cls32"].cpu().numpy()
+        act = net.forward(xd).cpu().numpy()
+        net.close()
+        c64, _, o64 = O.decode(x, Ws, bs, b, np.float64)
+        margin = O.top2_margin(o64)
+        tcls, tout = T.decode(x, Ws, bs, torch.float32)
+        for name, c, o in (("hip", cls, act), ("torch_cpu", tcls, tout)):
+            assert np.abs(o - o64).max() < TOL, name
+            bad = c != c64
+            assert not bad.any() or margin[bad].max() < TOL, name
+        flips = cls != tcls
+        assert flips.sum() <= max(2, len(x) // 20_000)          # measured: 0-2 per 2 M rows (profiles/r02/flip_rates.json)
+        assert not flips.any() or margin[flips].max() < TOL
