@@ -135,6 +135,20 @@ struct DecodeParams {
   int64_t first_row;
 };
 
+// K1 variants (template parameter VARIANT of mlp_decode_kernel; see nnv_mlp_decode.hip)
+constexpr int kVarGeneral = 0, kVarStream = 1, kVarLean = 2;
+// A/B build switches of K1's argmax (defaults = the shipped kernel)
+#ifndef NNV_DEFER_ARGMAX
+#define NNV_DEFER_ARGMAX 1
+#endif
+#ifndef NNV_KEEP_LDS
+#define NNV_KEEP_LDS 1
+#endif
+constexpr bool kDeferArgmax = NNV_DEFER_ARGMAX != 0;
+// Lean variant: the running winner's 16 raw accumulators are parked in a per-lane LDS slot by
+// exec-masked ds_write_b128 (no VALU) instead of 16 v_cndmask per class tile; 64 bytes per thread.
+constexpr bool kKeepLds = kDeferArgmax && NNV_KEEP_LDS != 0;
+
 constexpr int kMaxBins = 16;
 constexpr int kLdsTailBytes = 16 + kMaxBins * 16;  // work counter + per-bin {bit, frame, rows, pad}
 
@@ -146,6 +160,15 @@ struct LaunchPlan {
   int32_t lean_ok;         // the lean variant fits the LDS for this network
   int32_t out_in_lds;
   int32_t out_lds_tiles;
+};
+
+// one instantiation of nnv::mlp_decode_kernel (tables in nnv_mlp_decode.hip, lookup in nnv_mlp_launch.hip)
+using KernelFn = void (*)(const DecodeParams);
+struct KernelEntry {
+  int prec, g1, nhid, mta, mtb, mtc, nt;
+  bool act;
+  int variant;
+  KernelFn fn;
 };
 
 // nnv_capi.hip: NNV_OK iff `device` is the calling thread's current HIP device.  Every launch entry

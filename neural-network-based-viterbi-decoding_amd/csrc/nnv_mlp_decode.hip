@@ -29,18 +29,10 @@
 //  * Received soft bits are read once, as per-lane contiguous half rows
 //    (a wave reads one contiguous 32*n_in*4-byte span), prefetched one tile
 //    ahead; decoded classes are written as one 128-byte store per tile.
-#include <mutex>
-
 #include "nnv_internal.h"
 
 #ifndef NNV_CLASS_GROUP
 #define NNV_CLASS_GROUP 2
-#endif
-#ifndef NNV_DEFER_ARGMAX
-#define NNV_DEFER_ARGMAX 1
-#endif
-#ifndef NNV_KEEP_LDS
-#define NNV_KEEP_LDS 1
 #endif
 
 namespace nnv {
@@ -207,10 +199,6 @@ __device__ __forceinline__ void act16(f32x16 &acc) {
 // unsaturated z that round to the same fp32 tanh, |dtanh| < 6e-8, are told
 // apart here; that is far inside the 1e-5 near-tie rule of DESIGN.md.)
 constexpr float kTanhSat = 9.011f;
-constexpr bool kDeferArgmax = NNV_DEFER_ARGMAX != 0;
-// Lean variant: the running winner's 16 raw accumulators are parked in a per-lane LDS slot by
-// exec-masked ds_write_b128 (no VALU) instead of 16 v_cndmask per class tile; 64 bytes per thread.
-constexpr bool kKeepLds = kDeferArgmax && NNV_KEEP_LDS != 0;
 
 template <int G1, bool VEC_ONLY>
 __device__ __forceinline__ void load_x(const DecodeParams &p, int64_t tile,
@@ -257,7 +245,6 @@ __device__ unsigned long long g_diag[16];
 //   kVarLean     the benchmark / sweep call shape only: 16-byte aligned rows of an even, 4-divisible
 //                half width (p.xvec), class count a multiple of 32, classes + counters out (no
 //                int64 classes, no bit matrix, no per-SNR bins), class layer resident
-constexpr int kVarGeneral = 0, kVarStream = 1, kVarLean = 2;
 template <int PREC, int G1, int NHID, int MTA, int MTB, int MTC, int NT, bool WRITE_ACT, int VARIANT>
 __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   constexpr bool STREAM = VARIANT == kVarStream;
@@ -631,18 +618,16 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// host side: instantiation table, launch plan, launch
+// instantiation table of THIS translation unit.  The file is compiled twice (csrc/Makefile):
+//   -DNNV_TU_PREC=0  the fp32 kernels, scheduled with -mllvm -amdgpu-sched-strategy=max-ilp
+//                    (same-box A/B on the config-3 lean kernel: 24.75 -> 24.52 ms; the f16x3
+//                    kernels lose their fourth wave per SIMD under that strategy: 9.06 -> 9.54 ms)
+//   -DNNV_TU_PREC=1  the f16x3 kernels, default scheduler
+// nnv_mlp_launch.hip searches both tables.
 // ---------------------------------------------------------------------------
-namespace {
-
-using KernelFn = void (*)(const DecodeParams);
-
-struct KernelEntry {
-  int prec, g1, nhid, mta, mtb, mtc, nt;
-  bool act;
-  int variant;
-  KernelFn fn;
-};
+#ifndef NNV_TU_PREC
+#error "compile with -DNNV_TU_PREC=0 (fp32 kernels) or 1 (f16x3 kernels); see csrc/Makefile"
+#endif
 
 // decode kernels come in three variants (see the kernel); the debug (ACT) ones only as kVarStream
 #define NNV_K1(P, G1, NHID, A, B, C, NT, ACT, ST) \
@@ -662,8 +647,16 @@ struct KernelEntry {
   NNV_K(P, G1, 1, 4, 1, 1, 512, true), NNV_K(P, G1, 2, 4, 2, 1, 512, true),        \
   NNV_K(P, G1, 3, 4, 2, 1, 512, true)
 
-const KernelEntry kKernels[] = {
-    NNV_FAMILY(kPrecF32, 1),   NNV_FAMILY(kPrecF32, 2),   NNV_FAMILY(kPrecF32, 3),
+#if NNV_TU_PREC == 0
+extern const KernelEntry kKernelsF32[] = {
+    NNV_FAMILY(kPrecF32, 1), NNV_FAMILY(kPrecF32, 2), NNV_FAMILY(kPrecF32, 3),
+#ifdef NNV_DIAG
+    NNV_K(kPrecF32, 2, 3, 4, 2, 1, 256, false),
+#endif
+};
+extern const int kNumKernelsF32 = sizeof(kKernelsF32) / sizeof(kKernelsF32[0]);
+#else
+extern const KernelEntry kKernelsF16x3[] = {
     // f16x3: layer-1 k-steps = ceil(G1 / 2); G1 = 1, 2 share KS1 = 1 -> instantiate G1 = 2, 4
     NNV_FAMILY(kPrecF16x3, 2), NNV_FAMILY(kPrecF16x3, 4),
     // 3 waves per SIMD (<= 168 VGPRs): the f16x3 kernels need ~140
@@ -671,148 +664,15 @@ const KernelEntry kKernels[] = {
     NNV_K(kPrecF16x3, 2, 3, 4, 2, 1, 768, false), NNV_K(kPrecF16x3, 4, 1, 4, 1, 1, 768, false),
     NNV_K(kPrecF16x3, 4, 2, 4, 2, 1, 768, false), NNV_K(kPrecF16x3, 4, 3, 4, 2, 1, 768, false),
 #ifdef NNV_DIAG
-    NNV_K(kPrecF32, 2, 3, 4, 2, 1, 256, false), NNV_K(kPrecF16x3, 2, 3, 4, 2, 1, 256, false),
+    NNV_K(kPrecF16x3, 2, 3, 4, 2, 1, 256, false),
 #endif
 };
-
-const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act, bool lean = false) {
-  const int mta = s.mt[0];
-  const int mtb = s.nhid >= 2 ? s.mt[1] : 1;
-  const int mtc = s.nhid >= 3 ? s.mt[2] : 1;
-  const int variant = (act || s.streams != 0) ? kVarStream : (lean ? kVarLean : kVarGeneral);
-  for (const KernelEntry &k : kKernels)
-    if (k.prec == s.precision && k.g1 == s.g1 && k.nhid == s.nhid && k.mta == mta && k.mtb == mtb &&
-        k.mtc == mtc && k.nt == nt && k.act == act && k.variant == variant)
-      return &k;
-  return nullptr;
-}
-
-// Workgroup size: 1024 threads = 4 waves per SIMD (<= 128 VGPRs) when that
-// instantiation does not spill, else 512 (2 per SIMD).  NNV_THREADS overrides
-// (tuning / A-B runs only).
-int pick_threads_impl(const PackedShape &s) {
-  static const int forced = [] {
-    const char *e = getenv("NNV_THREADS");
-    const int v = e ? atoi(e) : 0;
-    return (v == 256 || v == 512 || v == 768 || v == 1024) ? v : 0;
-  }();
-  if (forced && find_kernel(s, forced, false)) return forced;
-  for (int nt : {1024, 768}) {  // most waves per SIMD whose instantiation does not spill
-    const KernelEntry *k = find_kernel(s, nt, false);
-    if (!k) continue;
-    hipFuncAttributes attr;
-    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) continue;
-    if (attr.localSizeBytes == 0) return nt;
-  }
-  return 512;
-}
-
-}  // namespace
-
-nnv_status decode_supported(const PackedShape &s) {
-  return find_kernel(s, 512, false) ? NNV_OK : NNV_ERR_UNSUPPORTED_SHAPE;
-}
-
-int decode_pick_threads(const PackedShape &s) { return pick_threads_impl(s); }
-
-int decode_kernel_vgprs(const PackedShape &s, int threads, bool lean) {
-  const KernelEntry *k = find_kernel(s, threads, false, lean);
-  if (!k) return 0;
-  hipFuncAttributes attr;
-  if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) return 0;
-  return attr.numRegs;
-}
-
-nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
-                       int lds_limit, int threads, LaunchPlan *plan) {
-  if (!find_kernel(s, 512, false)) return NNV_ERR_UNSUPPORTED_SHAPE;
-  const int64_t base_floats = s.hid_floats + s.bias_floats;
-  if (base_floats * 4 + kLdsTailBytes > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
-  // as many class-layer M-tiles as fit stay in LDS; the remaining ones are streamed from L2 per tile
-  const int64_t per_tile_bytes = static_cast<int64_t>(s.kt_out) * 4 * kFragGroupFloats * 4;
-  int64_t fit = (lds_limit - kLdsTailBytes - base_floats * 4) / per_tile_bytes;
-  if (fit > s.mt_out) fit = s.mt_out;
-  plan->out_lds_tiles = static_cast<int32_t>(fit);
-  plan->out_in_lds = fit == s.mt_out ? 1 : 0;
-  plan->lds_bytes = static_cast<int32_t>(base_floats * 4 + fit * per_tile_bytes) + kLdsTailBytes;  // + work counter, bin counters
-  plan->threads = threads;
-  // the lean variant parks the running argmax winner's accumulators in LDS: 64 bytes per thread
-  plan->lds_bytes_lean = plan->lds_bytes + (kKeepLds ? threads * 64 : 0);
-  plan->lean_ok = (plan->out_in_lds && plan->lds_bytes_lean <= lds_limit) ? 1 : 0;
-  // Persistent: one workgroup per CU.  Small batches are spread over as many CUs as they have
-  // tiles (one busy wave per CU, the others find no work and leave) rather than packed 16 tiles to
-  // a CU: BASELINE configs[0] (2,000 rows) 107 -> 39 us per launch, 20,000 rows 110 -> 63 us.
-  const int64_t n_tiles = (n_rows + kRowsPerTile - 1) / kRowsPerTile;
-  int64_t blocks = n_tiles;
-  if (blocks > num_cus) blocks = num_cus;
-  if (blocks < 1) blocks = 1;
-  plan->blocks = static_cast<int32_t>(blocks);
-  return NNV_OK;
-}
-
-namespace {
-// dynamic LDS above the default cap must be opted into, once per (device, kernel): the attribute
-// belongs to the function as loaded on ONE device
-nnv_status ensure_lds_optin(int device, const KernelEntry *k, int lds_bytes) {
-  constexpr int kN = sizeof(kKernels) / sizeof(kKernels[0]);
-  static int lds_set[kMaxDevices][kN] = {};
-  static std::mutex mu;  // prepack / launches may come from several host threads
-  if (device < 0 || device >= kMaxDevices) return NNV_ERR_INVALID_ARGUMENT;
-  const std::lock_guard<std::mutex> lock(mu);
-  const int idx = static_cast<int>(k - kKernels);
-  if (lds_set[device][idx] < lds_bytes) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k->fn),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
-      return NNV_ERR_HIP;
-    lds_set[device][idx] = lds_bytes;
-  }
-  return NNV_OK;
-}
-}  // namespace
-
-// Called from prepack (on the handle's device): every attribute a launch of this network needs is set
-// here, so that the launches themselves are pure kernel launches (capturable into a HIP graph from the
-// first call).
-nnv_status decode_prepare(const PackedShape &s, int num_cus, int lds_limit, int threads, int device) {
-  LaunchPlan plan;
-  const nnv_status st = decode_plan(s, 1 << 20, num_cus, lds_limit, threads, &plan);
-  if (st != NNV_OK) return st;
-  for (const int which : {0, 1, 2}) {  // decode, debug forward, lean decode
-    const KernelEntry *k = find_kernel(s, which == 1 ? 512 : plan.threads, which == 1, which == 2);
-    if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
-    if (which == 2 && !plan.lean_ok) continue;
-    const nnv_status e = ensure_lds_optin(device, k, which == 2 ? plan.lds_bytes_lean : plan.lds_bytes);
-    if (e != NNV_OK) return e;
-  }
-  return NNV_OK;
-}
-
-nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
-                         const LaunchPlan &plan, bool write_act, int device,
-                         hipStream_t stream) {
-  const int nt = write_act ? 512 : plan.threads;
-  static const bool no_lean = getenv("NNV_NO_LEAN") != nullptr;  // A/B runs only
-  const bool lean = !no_lean && plan.lean_ok && s.streams == 0 && !write_act && p.xvec && p.n_bins == 1 && !p.bits &&
-                    !p.cls64 && p.n_classes % 32 == 0;
-  const KernelEntry *k = find_kernel(s, nt, write_act, lean);
-  if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
-  const int lds_bytes = lean ? plan.lds_bytes_lean : plan.lds_bytes;
-  {
-    const nnv_status e = ensure_lds_optin(device, k, lds_bytes);
-    if (e != NNV_OK) return e;
-  }
-  int blocks = plan.blocks;
-  if (write_act) {  // 8 waves per workgroup in the debug variant
-    const int64_t b = (p.n_tiles + 7) / 8;
-    blocks = static_cast<int>(b < plan.blocks ? (b < 1 ? 1 : b) : plan.blocks);
-  }
-  hipLaunchKernelGGL(k->fn, dim3(blocks), dim3(nt), lds_bytes, stream, p);
-  return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
-}
+extern const int kNumKernelsF16x3 = sizeof(kKernelsF16x3) / sizeof(kKernelsF16x3[0]);
+#endif
 
 }  // namespace nnv
 
-#ifdef NNV_DIAG
+#if defined(NNV_DIAG) && NNV_TU_PREC == 0
 extern "C" int nnv_debug_read_stamps(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(nnv::g_diag), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
 }

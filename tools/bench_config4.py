@@ -19,10 +19,10 @@ ap.add_argument("--blocks-per-gpu", type=int, default=400_000)
 ap.add_argument("--precision", default="f32")
 ap.add_argument("--chunk-rows", type=int, default=1 << 25)
 args = ap.parse_args()
-rank, local_rank, world = nd.init_from_env()
-idx = local_rank % torch.cuda.device_count()
+idx = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()   # ONE device index per rank
 torch.cuda.set_device(idx)
 dev = torch.device("cuda", idx)
+rank, local_rank, world = nd.init_from_env(device_index=idx)
 w, b = mx.load_model(os.path.join(ROOT, "neural-network-based-viterbi-decoding_amd", "weights", "fnn_133171_b8_2dB.npz"))
 net = PackedMLP(*fv.weights_as_lists(w, b), device=dev, precision=args.precision)
 sig = [float(fv.DecoderConfig(snr_db=float(d)).sigma) for d in range(7)]

@@ -13,7 +13,7 @@ from nnviterbi_amd.decoder import Seq2SeqLSTM
 from oracle import rnn_oracle as R
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--blocks", type=int, default=1_000_000)   # configs[4] names 10M; 1M keeps the default run short
+ap.add_argument("--blocks", type=int, default=1_000_000)   # configs[4] names 10M (--blocks 10000000: ~120 GB of HBM); 1M keeps the default run short
 ap.add_argument("--block-len", type=int, default=256)
 ap.add_argument("--steps", type=int, default=3)
 args = ap.parse_args()
@@ -59,6 +59,9 @@ err = float(np.abs(r["logits"][:, :m].cpu().numpy() - ref64).max())
 print(json.dumps({
     "metric": f"recurrent decoder blocks/sec (rnn_viterbi LSTM(20) seq2seq forward, (133,171) block_len={L})",
     "value": B / (ms * 1e-3), "unit": "blocks/s", "ms_per_step": ms, "blocks": B, "dtype": "f32",
+    "config": {"workload": f"BASELINE configs[4]: recurrent path, (133,171) block_len={L}, {B} blocks, 1 GPU",
+               "cell": "LSTM, not GRU: BASELINE.json says GRU, the reference builds tf.contrib.rnn.LSTMCell "
+                       "(src/rnn_viterbi.py:289-318); the reference script itself cannot be imported (SURVEY F10)"},
     "weights": "Glorot-uniform init (TF defaults of the reference graph), untrained",
     "roofline": {"bound": "mfma", "achieved": flop * B / (ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                  "frac": flop * B / (ms * 1e-3) / 1e12 / 157.3, "algorithmic_flop_per_block": flop,

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Usage: tools/kernel_resources.py <file.hip> [extra hipcc flags]
+(nnv_mlp_decode.hip needs -DNNV_TU_PREC=0|1, and -mllvm -amdgpu-sched-strategy=max-ilp for the shipped fp32 build)
 One line per kernel: name, VGPRs, AGPRs, spills, scratch, occupancy."""
 import os, re, subprocess, sys
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
