@@ -197,7 +197,7 @@ class PackedMLP:
 
         The rows are streamed through a ring of page-locked staging slots owned by the packed
         network (allocated on the first call, reused afterwards): pageable -> pinned copies on
-        ``threads`` host threads (0 = the CPUs this process may use, at most 16), H2D DMA, the fused
+        ``threads`` host threads (0 = the CPUs this process may use, at most 8), H2D DMA, the fused
         decode launch and the D2H of the classes overlap on different chunks of ``chunk_rows`` rows.
         Returns ``(cls int64 [N], counters int64[4] | None)``."""
         x_host = np.ascontiguousarray(x_host, dtype=np.float32)

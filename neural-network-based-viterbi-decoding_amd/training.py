@@ -7,7 +7,12 @@ Restates the optimisation the reference builds in TensorFlow
     last op is tanh, and that tensor is passed as ``logits``)
     + beta * (l2(h1) + l2(h2) + l2(h3)), with tf.nn.l2_loss(w) = sum(w^2)/2;
     the output layer's weights are not regularised;
-  * Adam, learning rate from the config, TF defaults otherwise;
+  * Adam, learning rate from the config, TF defaults otherwise.  torch.optim.Adam places eps as
+    lr_t * m_hat / (sqrt(v_hat) + eps); TF-1 AdamOptimizer uses lr * sqrt(1-b2^t)/(1-b1^t) * m /
+    (sqrt(v) + eps), i.e. eps OUTSIDE the bias correction ("epsilon hat"): the two differ by a factor
+    sqrt(1-b2^t) on eps (1e-8), far below anything the decoded bits can see, so this is a restatement
+    of the recipe, not a bit-identical optimiser (and nothing of the reference's training can be
+    pinned anyway: no TensorFlow here);
   * contiguous, unshuffled, class-major mini-batches; the remainder that does
     not fill a batch is dropped (``int(num_training_samples / batch_size)``);
   * optional dropout after each hidden tanh (mixed_snr:596-627), evaluation
@@ -47,22 +52,26 @@ class GraphedStep:
         dev = params[0].device
         if dev.type != "cuda" or os.environ.get("NNV_NO_TRAIN_GRAPH"):   # the switch is for A/B tests
             return
-        try:
-            static = [t.clone() for t in example_inputs]
-            saved = [t.detach().clone() for t in params]
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):                       # warm-up steps outside the graph
-                    step(*static)
-            torch.cuda.current_stream().wait_stream(side)
-            with torch.no_grad():                        # undo the warm-up: weights and optimizer state
+        saved = [t.detach().clone() for t in params]
+
+        def restore():                                   # undo warm-up steps: weights and optimizer state
+            with torch.no_grad():
                 for t, v in zip(params, saved):
                     t.copy_(v)
                 for st in opt.state.values():
                     for v in st.values():
                         if torch.is_tensor(v):
                             v.zero_()
+
+        try:
+            static = [t.clone() for t in example_inputs]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):                       # warm-up steps outside the graph
+                    step(*static)
+            torch.cuda.current_stream().wait_stream(side)
+            restore()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):                    # records, does not execute
                 cost = step(*static)
@@ -71,6 +80,11 @@ class GraphedStep:
             if verbose:
                 print(f"(HIP graph capture of the training step unavailable: {e}; eager mode)")
             self._graph = None
+            try:                                         # the eager fallback must start from the initial
+                torch.cuda.synchronize()                 # state too, not 0-3 Adam steps into the run
+                restore()
+            except Exception:
+                pass
 
     @property
     def captured(self) -> bool:

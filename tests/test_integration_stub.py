@@ -38,3 +38,7 @@ def test_stub_decodes_like_the_oracle(cuda_device):
     assert pred.dtype == np.int64 and pred.shape == (5001,)
     ref = O.decode_c(x, Ws, bs, 7, want_bits=False)["cls"]
     assert (pred != ref).sum() <= 1
+    labels = np.random.RandomState(4).randint(0, 128, 5001)
+    pred2, counters = ns["decode"](ns["prepack"](Ws, bs), x, 7, labels=labels)
+    assert np.array_equal(pred2, pred)
+    assert np.array_equal(counters.astype(np.int64), O.error_counters(pred, labels, 7))

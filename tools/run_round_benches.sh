@@ -6,7 +6,12 @@ set -u
 tag=${1:-r02}
 out=gpurun_out/$tag
 mkdir -p $out
-run() { name=$1; shift; echo "== $name: $*"; "$@" > $out/$name.json 2> $out/$name.log || echo "   FAILED rc=$? (see $out/$name.log)"; tail -c 400 $out/$name.json; echo; }
+run() {  # stdout -> <name>.json (JSON lines only: gloo prints banners on stdout), stderr -> <name>.log
+  name=$1; shift; echo "== $name: $*"
+  "$@" > $out/$name.raw 2> $out/$name.log || echo "   FAILED rc=$? (see $out/$name.log)"
+  grep '^[{[]' $out/$name.raw > $out/$name.json; rm -f $out/$name.raw
+  tail -c 400 $out/$name.json; echo
+}
 run bench_n1_default python3 bench.py
 NNV_DIST_BACKEND=gloo run bench_2rank_rehearsal_one_gpu python3 bench.py --gpus 2 --blocks-per-gpu 4000000 --steps 5 --warmup 2 --no-cpu-baseline
 run bench_bitwise python3 tools/bench_bitwise.py
