@@ -151,7 +151,7 @@ int32_t nnv_mlp_decode_f32(const nnv_mlp_handle *h, const float *x_dev,
  *  labels_host   nullable [n_rows] int32
  *  cls32_host / cls64_host  nullable [n_rows] outputs
  *  counters_host nullable uint64[4], ADDED to; requires labels_host
- *  chunk_rows    rows per pipeline stage (0 = 2^21)
+ *  chunk_rows    rows per pipeline stage (0 = 64 MB worth of rows)
  *  n_threads     staging threads (0 = the CPUs this process may use, <= 8)
  * Calls on one handle are serialised.  Must be called with the handle's device
  * current.  Uses its own internal streams.

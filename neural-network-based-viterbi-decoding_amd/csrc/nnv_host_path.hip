@@ -12,8 +12,12 @@
 //
 // A plain hipMemcpy from pageable memory stages through the runtime's own pinned buffer on ONE
 // thread (~30 GB/s measured); here the pageable -> pinned copy is spread over T threads and runs
-// while the previous chunk is on the link and the one before that in the kernel, so the call is
-// bound by the link (x: 4 n_in bytes per row in, 4 bytes per row out), not by staging.
+// while the previous chunk is on the link and the one before that in the kernel.
+// Measured (tools/host_path_bench.py, 10 M blocks = 5.12 GB in, 0.32 GB out): 80-90 M blocks/s =
+// 44-49 GB/s moved, against 56.5 GB/s for a bare pinned H2D of the same rows; flat from 4 staging
+// threads up (the CPU share's path to DRAM carries source read + staging write + DMA read).  Handing
+// the caller's pageable rows to hipMemcpyAsync chunk by chunk instead (the runtime pins and unpins
+// each chunk in place) ran at 61-71 M blocks/s in the same harness, so the staged ring stays.
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -32,7 +36,7 @@
 namespace nnv {
 namespace {
 
-constexpr int kSlots = 3;
+constexpr int kSlots = 4;
 
 // Minimal fork-join pool: run(f) calls f(t) for t in [0, T) on T - 1 workers + the caller.
 class Pool {
@@ -241,7 +245,9 @@ extern "C" int32_t nnv_mlp_decode_host_f32(nnv_mlp_handle *h, const float *x_hos
   const std::lock_guard<std::mutex> call_lock(c.mu);
 
   const int n_in = h->shape.n_in;
-  int64_t m = chunk_rows > 0 ? chunk_rows : (1LL << 21);
+  // default stage: 64 MB of rows (measured on the 10 M-block workload, 4 slots: 64 MB 86-90 M blocks/s,
+  // 128-512 MB 79-81 M, 4 MB 38 M: per-chunk launch/enqueue cost below, cache footprint above)
+  int64_t m = chunk_rows > 0 ? chunk_rows : std::max<int64_t>(32, (64LL << 20) / (4LL * n_in));
   m = std::min(m, n_rows);
   m = (m + 31) / 32 * 32;  // whole wave tiles per chunk
   const bool labels = labels_host != nullptr;

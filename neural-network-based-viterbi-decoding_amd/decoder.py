@@ -190,7 +190,7 @@ class PackedMLP:
         return {"cls32": cls32, "counters": counters}
 
     def decode_host(self, x_host: np.ndarray, labels_host: Optional[np.ndarray] = None,
-                    tile_bits: Optional[int] = None, chunk_rows: int = 1 << 21, threads: int = 0):
+                    tile_bits: Optional[int] = None, chunk_rows: int = 0, threads: int = 0):
         """The reference's call shape: a HOST ``test_set`` in, host predictions out
         (``predictions_tensor.eval(feed_dict={x: test_set})``, src/fnn_viterbi.py:610), as one
         synchronous C-ABI call (``nnv_mlp_decode_host_f32``).
@@ -198,7 +198,8 @@ class PackedMLP:
         The rows are streamed through a ring of page-locked staging slots owned by the packed
         network (allocated on the first call, reused afterwards): pageable -> pinned copies on
         ``threads`` host threads (0 = the CPUs this process may use, at most 8), H2D DMA, the fused
-        decode launch and the D2H of the classes overlap on different chunks of ``chunk_rows`` rows.
+        decode launch and the D2H of the classes overlap on different chunks of ``chunk_rows`` rows
+        (0 = 64 MB worth of rows).
         Returns ``(cls int64 [N], counters int64[4] | None)``."""
         x_host = np.ascontiguousarray(x_host, dtype=np.float32)
         if x_host.ndim != 2 or x_host.shape[1] != self.n_input:
@@ -218,7 +219,7 @@ class PackedMLP:
                 None if lab_host is None else ctypes.c_void_p(lab_host.ctypes.data), None,
                 ctypes.c_void_p(cls64.ctypes.data),
                 None if counters is None else ctypes.c_void_p(counters.ctypes.data),
-                int(max(1, chunk_rows)), int(threads))
+                int(max(0, chunk_rows)), int(threads))
         _cabi.check(st, "nnv_mlp_decode_host_f32")
         return cls64, (None if counters is None else counters.astype(np.int64))
 
