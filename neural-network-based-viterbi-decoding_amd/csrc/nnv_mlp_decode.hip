@@ -199,6 +199,12 @@ __device__ __forceinline__ void act16(f32x16 &acc) {
 // unsaturated z that round to the same fp32 tanh, |dtanh| < 6e-8, are told
 // apart here; that is far inside the 1e-5 near-tie rule of DESIGN.md.)
 constexpr float kTanhSat = 9.011f;
+// from here up distinct pre-activations share an fp32 tanh value over spans wider than 0.25 in z
+constexpr float kFlatBand = 7.9f;
+#ifndef NNV_FLAT_TOP
+#define NNV_FLAT_TOP 1
+#endif
+constexpr bool kFlatTopPath = NNV_FLAT_TOP != 0;
 
 template <int G1, bool VEC_ONLY>
 __device__ __forceinline__ void load_x(const DecodeParams &p, int64_t tile,
@@ -538,6 +544,36 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     if constexpr (kDeferArgmax) {
       const unsigned t = scan_first(keep, best);
       bidx = 32 * btile + 4 * half + 8 * static_cast<int>(t >> 2) + static_cast<int>(t & 3u);
+    }
+
+    // ---------------- flat top of fp32 tanh: decide as the reference does -----
+    // Below kFlatBand the clamped pre-activations order the classes exactly as their tanh'd values do,
+    // up to differences of one fp32 ulp of the output (6e-8: far inside the 1e-5 near-tie rule).  Above
+    // it fp32 tanh has WIDE flat steps (z in [8.32, 9.01) all give 1 - 2^-24, [7.97, 8.32) 1 - 2^-23 ...):
+    // the reference's argmax over the tanh'd outputs then returns the LOWEST tied index, the clamped
+    // pre-activations the largest z.  Such rows (none in 80 M at 2 dB with the trained network: max z
+    // 4.4) take this wave-uniform cold path: the class layer once more, weights from global memory,
+    // first maximum over tanh_f32(z) -- the very values nnv_mlp_forward_f32 writes, so decode ==
+    // argmax_first(forward) there, as in the layer-at-a-time path (row_argmax_kernel) and the oracle.
+    if constexpr (kFlatTopPath) {
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(best >= kFlatBand) != 0, 0)) {
+        float tb = -__builtin_inff();
+        int ti = 0;
+        for (int mt = 0; mt < p.mt_out; ++mt) {
+          f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
+          acc = dense_tile<PREC, KT_OUT>(hlast, p.wpack + HIDF + static_cast<int64_t>(mt) * KT_OUT * 4 * kFragGroupFloats + lo, acc);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ci = 32 * mt + 4 * half + 8 * (r >> 2) + (r & 3);
+            const float t = tanh_f32(acc[r]);
+            const bool c = ci < p.n_classes && t > tb;
+            tb = c ? t : tb;
+            ti = c ? ci : ti;
+          }
+        }
+        best = tb;
+        bidx = ti;
+      }
     }
 
     NNV_STAMP(4);  // class layer

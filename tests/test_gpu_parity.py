@@ -299,6 +299,42 @@ def test_saturated_outputs_resolve_to_the_first_maximum(cuda_device, precision):
         net.close()
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_flat_top_of_fp32_tanh_resolves_like_the_reference(cuda_device, precision):
+    """z = 8.8 and z = 8.9 both give tanh = 1 - 2^-24 in fp32: the reference's argmax over the tanh'd
+    outputs returns the LOWER index even when it holds the smaller pre-activation.  The fused kernel
+    decides on clamped pre-activations below the flat band and on its own tanh'd values inside it,
+    so it, its forward output, the layer-at-a-time path and the oracle all agree."""
+    from nnviterbi_amd.decoder import WideMLP
+    zero = [np.zeros((16, 128), np.float32), np.zeros((128, 64), np.float32), np.zeros((64, 32), np.float32),
+            np.zeros((32, 256), np.float32)]
+    xs = np.zeros((70, 16), np.float32)
+    x = torch.from_numpy(xs).cuda()
+    # fp32 tanh just below 1.0 is 1 - k 2^-24: k = 0 for z > 9.05, 1 on (8.46, 9.0), 2 on (8.21, 8.46),
+    # 3 on (8.04, 8.21), 4 on (7.91, 8.04); every z below sits well inside its step
+    cases = [({3: 8.8, 77: 8.9}, 3),              # same step, the lower index has the SMALLER z
+             ({200: 8.6, 9: 8.3, 250: 8.9}, 200),  # two on the top step (different class tiles), one a step lower
+             ({40: 8.15, 10: 8.1}, 10),            # a lower step, again the smaller z wins by index
+             ({5: 9.3, 2: 8.9}, 5),                # exactly 1.0 beats 1 - 2^-24 whatever the index
+             ({100: 8.0, 101: 8.3}, 101)]          # different steps: the larger tanh wins
+    for hot, want in cases:
+        bo = np.full(256, -1.0, np.float32)
+        for k, v in hot.items():
+            bo[k] = v
+        bs = [np.zeros(128, np.float32), np.zeros(64, np.float32), np.zeros(32, np.float32), bo]
+        net = PackedMLP(zero, bs, precision=precision)
+        cls = net.decode(x, tile_bits=8)["cls32"].cpu().numpy()
+        fwd = net.forward(x).cpu().numpy()
+        net.close()
+        assert np.array_equal(cls, np.argmax(fwd, axis=1)), hot      # decode == argmax_first(forward)
+        ref = O.decode_c(xs, zero, bs, 8, want_act=True)
+        assert set(cls.tolist()) == {want} and set(ref["cls"].tolist()) == {want}, hot
+        assert np.abs(fwd - ref["act"]).max() < 2e-7
+        wide = WideMLP(zero, bs, activation="tanh", precision="f32")
+        assert np.array_equal(wide.decode(x)["cls32"].cpu().numpy(), cls), hot
+        wide.close()
+
+
 def test_unsupported_network_fails_loudly(cuda_device):
     with pytest.raises(nnviterbi_amd.NNViterbiError):
         PackedMLP(*_net([16, 512, 256], 0))          # no kernel instantiation for this width
