@@ -3,7 +3,7 @@
 #   tools/profile_round.sh <tag>      -> gpurun_out/prof_<tag>/...
 # 1. rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`
 # 2. separate --pmc passes (never combined with tracing): FETCH_SIZE | WRITE_SIZE | SQ groups
-# 3. the secondary paths' kernel stats (sliding-window, recurrent)
+# 3. the secondary paths' kernel stats (sliding-window, recurrent, bit-wise bank)
 # Summarise afterwards with tools/summarize_pmc.py and copy what is to be judged into profiles/.
 set -u
 tag=${1:-r01}
@@ -24,4 +24,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_seq -o run --
 echo "seq done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_rnn -o run -- python3 tools/bench_rnn.py > $out/bench_rnn.json 2> $out/trace_rnn.log
 echo "rnn done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_bitwise -o run -- python3 tools/bench_bitwise.py > $out/bench_bitwise.json 2> $out/trace_bitwise.log
+echo "bitwise done"
 find $out -name "*kernel_trace.csv" -size +3M -delete   # keep the summaries, not multi-MB traces
