@@ -49,7 +49,10 @@ nnv_status shape_from_desc(const nnv_mlp_desc *net, int32_t precision, PackedSha
   int mts = s->mt_out;
   for (int i = 0; i < s->nhid; ++i) mts += s->mt[i];
   s->bias_floats = 32LL * mts;
-  s->streams = (s->hid_floats + s->out_floats + s->bias_floats) * 4 + nnv::kLdsTailBytes > kLdsLimitBytes ? 1 : 0;
+  // the class layer is streamed when the whole network + the argmax winner slots (64 B x 1024 threads)
+  // do not fit the LDS together
+  const int64_t slots = nnv::kKeepLds ? 1024 * 64 : 0;
+  s->streams = (s->hid_floats + s->out_floats + s->bias_floats) * 4 + nnv::kLdsTailBytes + slots > kLdsLimitBytes ? 1 : 0;
   return nnv::decode_supported(*s);
 }
 
@@ -303,12 +306,7 @@ int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision, nnv_mlp_h
   }
   h->threads = nnv::decode_pick_threads(s);
   const nnv_status prep = nnv::decode_prepare(s, h->num_cus, h->lds_limit, h->threads, dev);
-  {
-    LaunchPlan lp;
-    const bool lean = nnv::decode_plan(s, 1 << 20, h->num_cus, h->lds_limit, h->threads, &lp) == NNV_OK &&
-                      lp.lean_ok && s.streams == 0 && s.n_classes % 32 == 0;
-    h->vgprs = nnv::decode_kernel_vgprs(s, h->threads, lean);
-  }
+  h->vgprs = nnv::decode_kernel_vgprs(s, h->threads, s.streams == 0 && s.n_classes % 32 == 0);
   if (prep != NNV_OK) {
     (void)hipFree(h->wpack_dev);
     delete h;
@@ -438,7 +436,7 @@ int32_t nnv_mlp_launch_info(const nnv_mlp_handle *h, int64_t n_rows, int32_t *in
   if (st != NNV_OK) return st;
   info_host[0] = plan.threads;
   info_host[1] = plan.blocks;
-  info_host[2] = (plan.lean_ok && h->shape.streams == 0 && h->shape.n_classes % 32 == 0) ? plan.lds_bytes_lean : plan.lds_bytes;
+  info_host[2] = plan.lds_bytes;
   info_host[3] = h->vgprs;
   info_host[4] = plan.out_in_lds;
   info_host[5] = nnv::kRowsPerTile;

@@ -145,8 +145,10 @@ constexpr int kVarGeneral = 0, kVarStream = 1, kVarLean = 2;
 #define NNV_KEEP_LDS 1
 #endif
 constexpr bool kDeferArgmax = NNV_DEFER_ARGMAX != 0;
-// Lean variant: the running winner's 16 raw accumulators are parked in a per-lane LDS slot by
-// exec-masked ds_write_b128 (no VALU) instead of 16 v_cndmask per class tile; 64 bytes per thread.
+// General and lean variants (LDS-resident networks): the running argmax winner's 16 raw accumulators are
+// parked in a per-lane LDS slot by exec-masked ds_write_b128 (no VALU) instead of 16 v_cndmask per class
+// tile: 64 bytes per thread, reserved by decode_plan.  The stream variant keeps them in registers
+// (0 = A/B builds: every variant does).
 constexpr bool kKeepLds = kDeferArgmax && NNV_KEEP_LDS != 0;
 
 constexpr int kMaxBins = 16;
@@ -156,8 +158,6 @@ struct LaunchPlan {
   int32_t threads;
   int32_t blocks;
   int32_t lds_bytes;
-  int32_t lds_bytes_lean;  // of the lean variant (adds its per-thread argmax slots)
-  int32_t lean_ok;         // the lean variant fits the LDS for this network
   int32_t out_in_lds;
   int32_t out_lds_tiles;
 };

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     // class tile (51 ops x 8 tiles; -DNNV_DEFER_ARGMAX=0 restores that for A/B builds).
     f32x16 keep;
     int btile = 0;
-    constexpr bool KEEP_LDS = LEAN && kKeepLds;
+    constexpr bool KEEP_LDS = !STREAM && kKeepLds;
     // [wave][q][lane][4 floats]: consecutive lanes write consecutive 16-byte pieces (conflict free)
     float *const keep_slot = reinterpret_cast<float *>(bin_ctr + kMaxBins * 4) + (threadIdx.x >> 6) * 1024 + lane * 4;
     auto scan_first = [&](const f32x16 &acc, float m) -> unsigned {

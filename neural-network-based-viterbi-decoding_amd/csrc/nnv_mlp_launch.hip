@@ -39,7 +39,7 @@ const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act, bool lean
 }
 
 // Workgroup size: 1024 threads = 4 waves per SIMD (<= 128 VGPRs) when that
-// instantiation does not spill, else 512 (2 per SIMD).  NNV_THREADS overrides
+// instantiation does not spill (more than a handful of registers), else 512 (2 per SIMD).  NNV_THREADS overrides
 // (tuning / A-B runs only).
 int pick_threads_impl(const PackedShape &s) {
   static const int forced = [] {
@@ -53,7 +53,7 @@ int pick_threads_impl(const PackedShape &s) {
     if (!k) continue;
     hipFuncAttributes attr;
     if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) continue;
-    if (attr.localSizeBytes == 0) return nt;
+    if (attr.localSizeBytes <= 32) return nt;  // up to 8 spilled dwords cost less than a wave per SIMD
   }
   return 512;
 }
@@ -78,18 +78,21 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
                        int lds_limit, int threads, LaunchPlan *plan) {
   if (!find_kernel(s, 512, false)) return NNV_ERR_UNSUPPORTED_SHAPE;
   const int64_t base_floats = s.hid_floats + s.bias_floats;
-  if (base_floats * 4 + kLdsTailBytes > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
+  // Resident networks (general / lean variants) park the running argmax winner's accumulators in LDS, 64
+  // bytes per thread (shape_from_desc made the network a streaming one if they do not fit beside it).  The
+  // stream variant keeps the winner in registers: its LDS is better spent on class-layer tiles (configs[1],
+  // same-box A/B: 80.1 M blocks/s with 13 of 32 tiles resident, 76-78 M with the slots and 5-9 tiles).
+  const int64_t scratch = (kKeepLds && s.streams == 0) ? static_cast<int64_t>(threads) * 64 : 0;
+  if (base_floats * 4 + kLdsTailBytes + scratch > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
   // as many class-layer M-tiles as fit stay in LDS; the remaining ones are streamed from L2 per tile
   const int64_t per_tile_bytes = static_cast<int64_t>(s.kt_out) * 4 * kFragGroupFloats * 4;
-  int64_t fit = (lds_limit - kLdsTailBytes - base_floats * 4) / per_tile_bytes;
+  int64_t fit = (lds_limit - kLdsTailBytes - scratch - base_floats * 4) / per_tile_bytes;
   if (fit > s.mt_out) fit = s.mt_out;
+  if (s.streams == 0 && fit < s.mt_out) return NNV_ERR_UNSUPPORTED_SHAPE;  // shape_from_desc sized it without the slots
   plan->out_lds_tiles = static_cast<int32_t>(fit);
   plan->out_in_lds = fit == s.mt_out ? 1 : 0;
-  plan->lds_bytes = static_cast<int32_t>(base_floats * 4 + fit * per_tile_bytes) + kLdsTailBytes;  // + work counter, bin counters
+  plan->lds_bytes = static_cast<int32_t>(base_floats * 4 + fit * per_tile_bytes + kLdsTailBytes + scratch);
   plan->threads = threads;
-  // the lean variant parks the running argmax winner's accumulators in LDS: 64 bytes per thread
-  plan->lds_bytes_lean = plan->lds_bytes + (kKeepLds ? threads * 64 : 0);
-  plan->lean_ok = (plan->out_in_lds && plan->lds_bytes_lean <= lds_limit) ? 1 : 0;
   // Persistent: one workgroup per CU.  Small batches are spread over as many CUs as they have
   // tiles (one busy wave per CU, the others find no work and leave) rather than packed 16 tiles to
   // a CU: BASELINE configs[0] (2,000 rows) 107 -> 39 us per launch, 20,000 rows 110 -> 63 us.
@@ -129,10 +132,10 @@ nnv_status decode_prepare(const PackedShape &s, int num_cus, int lds_limit, int 
   const nnv_status st = decode_plan(s, 1 << 20, num_cus, lds_limit, threads, &plan);
   if (st != NNV_OK) return st;
   for (const int which : {0, 1, 2}) {  // decode, debug forward, lean decode
+    if (which == 2 && s.streams != 0) continue;
     const KernelEntry *k = find_kernel(s, which == 1 ? 512 : plan.threads, which == 1, which == 2);
     if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
-    if (which == 2 && !plan.lean_ok) continue;
-    const nnv_status e = ensure_lds_optin(device, k, which == 2 ? plan.lds_bytes_lean : plan.lds_bytes);
+    const nnv_status e = ensure_lds_optin(device, k, plan.lds_bytes);
     if (e != NNV_OK) return e;
   }
   return NNV_OK;
@@ -143,11 +146,11 @@ nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
                          hipStream_t stream) {
   const int nt = write_act ? 512 : plan.threads;
   static const bool no_lean = getenv("NNV_NO_LEAN") != nullptr;  // A/B runs only
-  const bool lean = !no_lean && plan.lean_ok && s.streams == 0 && !write_act && p.xvec && p.n_bins == 1 && !p.bits &&
-                    !p.cls64 && p.n_classes % 32 == 0;
+  const bool lean = !no_lean && s.streams == 0 && !write_act && p.xvec && p.n_bins == 1 && !p.bits && !p.cls64 &&
+                    p.n_classes % 32 == 0;
   const KernelEntry *k = find_kernel(s, nt, write_act, lean);
   if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
-  const int lds_bytes = lean ? plan.lds_bytes_lean : plan.lds_bytes;
+  const int lds_bytes = plan.lds_bytes;
   {
     const nnv_status e = ensure_lds_optin(device, k, lds_bytes);
     if (e != NNV_OK) return e;
