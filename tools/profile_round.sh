@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON the GPU box (via gpurun): collects the evidence bench.py's roofline object cites.
 #   tools/profile_round.sh <tag>      -> gpurun_out/prof_<tag>/...
-# 1. rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`
+# 1. rocprofv3 --kernel-trace --stats of the default `python3 bench.py` (the command the driver runs)
 # 2. separate --pmc passes (never combined with tracing): FETCH_SIZE | WRITE_SIZE | SQ groups
 # 3. the secondary paths' kernel stats (sliding-window, recurrent, bit-wise bank)
 # Summarise afterwards with tools/summarize_pmc.py and copy what is to be judged into profiles/.
@@ -10,7 +10,7 @@ tag=${1:-r01}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python3 bench.py"   # the driver's own default command (K = 20, W = 3, cpu_baseline leg included)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o run -- $BENCH > $out/bench_under_rocprof.json 2> $out/trace.log
 echo "trace done: $(tail -c 300 $out/bench_under_rocprof.json | head -c 200)"
 PMCBENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"

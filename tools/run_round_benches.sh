@@ -9,7 +9,7 @@ mkdir -p $out
 run() {  # stdout -> <name>.json (JSON lines only: gloo prints banners on stdout), stderr -> <name>.log
   name=$1; shift; echo "== $name: $*"
   "$@" > $out/$name.raw 2> $out/$name.log || echo "   FAILED rc=$? (see $out/$name.log)"
-  grep '^[{[]' $out/$name.raw > $out/$name.json; rm -f $out/$name.raw
+  grep '^{' $out/$name.raw > $out/$name.json; rm -f $out/$name.raw
   tail -c 400 $out/$name.json; echo
 }
 run bench_n1_default python3 bench.py
