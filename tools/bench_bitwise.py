@@ -68,6 +68,11 @@ for p in (0, P // 2, P - 1):
     refp = O.decode_c(xs, [models[p][0], models[p][2]], [models[p][1], models[p][3]], 1, want_bits=False,
                       activation="relu")
     mismP += int((refp["cls"] != bitsP[p]).sum())
+# ---- one position through the fused kernel (32-column tile + head in the epilogue) ------------
+bank1 = BitwiseBank(models[:1])
+ms1f, r1f = timed(lambda: bank1.decode(x), args.steps)
+ref0 = O.decode_c(xs, [models[0][0], models[0][2]], [models[0][1], models[0][3]], 1, want_bits=False, activation="relu")
+mism1f = int((ref0["cls"] != r1f["bits"][0, :m].cpu().numpy()).sum())
 flop_row = 2 * cfg.n_input * cfg.n_hidden_1 * P + 2 * cfg.n_hidden_1 * 2 * P
 bytes_row = 4 * cfg.n_input + P
 print(json.dumps({
@@ -80,6 +85,13 @@ print(json.dumps({
                      "frac": in_bytes * n / (ms1 * 1e-3) / 8.0e12, "algorithmic_bytes_per_row": in_bytes},
         "parity_sample": {"rows": m, "class_mismatches": mism1},
         "ms_for_all_positions_this_way": ms1 * P,
+    },
+    "single_fused": {
+        "what": "one bit position, first layer + head in ONE launch (BitwiseBank of 1)", "value": n / (ms1f * 1e-3),
+        "unit": "rows/s", "ms_per_step": ms1f,
+        "roofline": {"bound": "hbm", "achieved": (4 * cfg.n_input + 1) * n / (ms1f * 1e-3) / 1e9, "peak": 8000.0,
+                     "unit": "GB/s", "frac": (4 * cfg.n_input + 1) * n / (ms1f * 1e-3) / 8.0e12},
+        "parity_sample": {"rows": m, "class_mismatches": mism1f},
     },
     "bank": {
         "what": f"{P} positions in one fused launch (decoder.BitwiseBank)", "positions": P,
