@@ -188,6 +188,22 @@ def test_bitwise_train_and_evaluate_end_to_end(cuda_device, tmp_path):
     assert sorted(np.load(str(tmp_path / "bw.npz")).files)[0] == "bias_h1"
 
 
+def test_relu_network_on_the_layer_at_a_time_path(cuda_device):
+    """WideMLP(activation="relu"), narrow fp32 layer (32-column tiles) + head kernel: the generic path for
+    ReLU networks (bw.predict itself now takes the fused single-launch kernel for n_hidden <= 32)."""
+    for dims in ([1036, 30, 2], [300, 48, 2]):
+        Ws, bs = _net(dims, 4)
+        bs[-1] = np.array([-0.2, 0.05], np.float32)
+        x = np.trunc(np.random.RandomState(3).randn(3001, dims[0]) * 1.5).astype(np.float32)
+        net = WideMLP(Ws, bs, activation="relu")
+        r = net.decode(torch.from_numpy(x).cuda(), want_act=True)
+        c64, _, o64 = O.decode(x, Ws, bs, 1, np.float64, activation="relu")
+        assert np.abs(r["act"].cpu().numpy() - o64).max() < 2e-5 * max(1.0, np.abs(o64).max())
+        bad = r["cls32"].cpu().numpy() != c64
+        assert not bad.any() or O.top2_margin(o64)[bad].max() < 1e-4
+        net.close()
+
+
 def test_relu_network_in_f16x3_precision(cuda_device):
     dims = [1036, 30, 2]
     Ws, bs = _net(dims, 9)
