@@ -229,6 +229,21 @@ __device__ __forceinline__ void load_x(const DecodeParams &p, int64_t tile,
   }
 }
 
+// Lean variant (16-byte aligned rows, half width a multiple of 4 floats = exactly XG chunks): the tile's
+// base is a scalar 64-bit address, the lane's byte offset a 32-bit value that is the same for every full
+// tile (the caller passes the clamped offsets of the last, possibly partial tile instead): no 64-bit
+// multiplies, no per-chunk guards and no zero fills on the vector ALU per tile.
+template <int XG>
+__device__ __forceinline__ void load_x_lean(const char *tile_base, unsigned lane_off, float (&xr)[4 * XG]) {
+  const f32x4 *px = reinterpret_cast<const f32x4 *>(tile_base + lane_off);
+#pragma unroll
+  for (int g = 0; g < XG; ++g) {
+    const f32x4 v = px[g];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xr[4 * g + e] = v[e];
+  }
+}
+
 #ifdef NNV_DIAG  // separate diagnostic build only: per-phase s_memtime sums of (block 0, wave 0)
 __device__ unsigned long long g_diag[16];
 #define NNV_STAMP(slot)                                                                  \
@@ -312,7 +327,19 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 
   unsigned bit_err = 0, frame_err = 0;
   float xr[XN];
-  if (tile < p.n_tiles) load_x<XG, LEAN>(p, tile, j, half, xr);
+  // lean variant: per-lane byte offsets of a full tile and of the last (possibly partial) one
+  const int64_t x_tile_bytes = static_cast<int64_t>(kRowsPerTile) * p.n_in * 4;
+  const unsigned x_off_full = static_cast<unsigned>(j * p.n_in + half * p.bp) * 4u;
+  const int64_t last_rows = p.n_rows - (p.n_tiles - 1) * kRowsPerTile;  // 1..32
+  const unsigned x_off_last = static_cast<unsigned>((j < last_rows ? j : static_cast<int>(last_rows) - 1) * p.n_in + half * p.bp) * 4u;
+  auto fetch_x = [&](int64_t t, float (&dst)[XN]) {
+    if constexpr (LEAN && PREC == kPrecF32) {
+      load_x_lean<XG>(reinterpret_cast<const char *>(p.x) + t * x_tile_bytes, t == p.n_tiles - 1 ? x_off_last : x_off_full, dst);
+    } else {
+      load_x<XG, LEAN>(p, t, j, half, dst);
+    }
+  };
+  if (tile < p.n_tiles) fetch_x(tile, xr);
 #ifdef NNV_DIAG
   unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long diag_last = __builtin_amdgcn_s_memtime();
@@ -370,7 +397,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     if constexpr (NHID == 1) {
 #pragma unroll
       for (int mt = 0; mt < MTA; ++mt) ha[mt].set(layer1_tile(mt));
-      if (next_tile < p.n_tiles) load_x<XG, LEAN>(p, next_tile, j, half, xn);
+      if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
       NNV_STAMP(1);
     } else {
       f32x16 acc2[MTB];
@@ -385,7 +412,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
           acc2[mt] = dense_tile<PREC, 1>(a, lds + W1F + (mt * MTA + kt) * 4 * kFragGroupFloats + lo, acc2[mt]);
       }
       NNV_STAMP(1);  // layer 1 + layer 2 MFMAs
-      if (next_tile < p.n_tiles) load_x<XG, LEAN>(p, next_tile, j, half, xn);
+      if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
 #pragma unroll
       for (int mt = 0; mt < MTB; ++mt) {
         act16<PREC>(acc2[mt]);

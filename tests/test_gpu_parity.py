@@ -128,6 +128,31 @@ def test_large_random_batch_flip_rate(cuda_device, precision):
     net.close()
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 63, 4099, 65537])
+def test_lean_variant_equals_general_variant(cuda_device, n, precision):
+    """The benchmark call shape (classes + counters only, 16-byte aligned rows, class count a multiple
+    of 32) runs the 'lean' kernel instantiation with its own row addressing (scalar tile base + fixed
+    per-lane offsets, clamped offsets in the last partial tile); every other output combination runs
+    the general one.  Same classes and counters, ragged tails included."""
+    dims, b = [16, 128, 64, 32, 256], 8
+    Ws, bs = _net(dims, seed=77)
+    rng = np.random.RandomState(n)
+    x = torch.from_numpy((rng.randn(n, 16) * 1.1).astype(np.float32)).cuda()
+    lab = torch.from_numpy(rng.randint(0, 256, n).astype(np.int32)).cuda()
+    net = PackedMLP(Ws, bs, precision=precision)
+    lean = net.decode(x, labels=lab, tile_bits=b)                                   # cls32 + counters
+    gen = net.decode(x, labels=lab, tile_bits=b, want_cls64=True, want_bits=True)   # every output
+    assert torch.equal(lean["cls32"], gen["cls32"]) and torch.equal(lean["counters"], gen["counters"])
+    ref = O.decode_c(x.cpu().numpy(), Ws, bs, b, labels=lab.cpu().numpy(), want_bits=False)
+    assert (lean["cls32"].cpu().numpy() != ref["cls"]).sum() <= max(1, n // 1000)
+    # a view that starts mid-buffer (still 16-byte aligned rows): base pointer arithmetic of the lean loader
+    if n > 40:
+        sub = net.decode(x[7:], labels=lab[7:].contiguous(), tile_bits=b)
+        assert torch.equal(sub["cls32"], lean["cls32"][7:])
+    net.close()
+
+
 def test_empty_input_is_a_noop(cuda_device):
     Ws, bs = _net([16, 128, 64, 32, 256], 1)
     net = PackedMLP(Ws, bs)
