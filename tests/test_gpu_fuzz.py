@@ -1,4 +1,4 @@
-"""Seeded shape fuzz of the three HIP paths against the oracle (MI355X).
+"""Seeded shape fuzz of the HIP paths against the oracle (MI355X).
 
 Every case draws a network shape, a row count and inputs from a fixed seed, runs the HIP path in
 both precision modes and applies the stated tolerances of the dedicated suites:
@@ -64,7 +64,39 @@ def test_fused_decoder_random_shapes(cuda_device, seed, precision):
     assert np.array_equal(r["cls64"].cpu().numpy(), cls.astype(np.int64))
     assert np.array_equal(r["bits"].cpu().numpy(), O.class_to_bits(cls, b))
     assert np.array_equal(r["counters"].cpu().numpy(), O.error_counters(cls, labels, b))
+    # the classes+counters call shape (lean instantiation where the shape allows it) and the host-array
+    # entry (pinned ring, random chunking / thread count) must give the very same classes and counters
+    lean = net.decode(xd, labels=torch.from_numpy(labels).cuda(), tile_bits=b)
+    assert np.array_equal(lean["cls32"].cpu().numpy(), cls) and torch.equal(lean["counters"], r["counters"])
+    hc, hcnt = net.decode_host(x, labels, b, chunk_rows=int(rng.choice([1, 33, 100, 4096])), threads=int(rng.randint(0, 4)))
+    assert np.array_equal(hc, cls.astype(np.int64)) and np.array_equal(hcnt, r["counters"].cpu().numpy())
     net.close()
+
+
+@pytest.mark.parametrize("seed", range(8 * SCALE))
+def test_bitwise_bank_random_shapes(cuda_device, seed):
+    """K4b: random input width (even), hidden width <= 32, 1..40 positions, ragged rows."""
+    from nnviterbi_amd.decoder import BitwiseBank
+    rng = np.random.RandomState(4000 + seed)
+    K, H = int(2 * rng.randint(1, 300)), int(rng.randint(1, 33))
+    P, n = int(rng.randint(1, 41)), int(rng.choice([1, 63, 128, 129, 1000, 2500]))
+    models = []
+    for _ in range(P):
+        Ws, bs = _net([K, H, 2], rng, bias_scale=0.3)
+        models.append((Ws[0], bs[0], Ws[1], bs[1]))
+    x = np.trunc(rng.randn(n, K) * 1.5).astype(np.float32)
+    labels = (rng.rand(P, n) > 0.5).astype(np.uint8)
+    bank = BitwiseBank(models)
+    r = bank.decode(torch.from_numpy(x).cuda(), labels=torch.from_numpy(labels).cuda(), want_act=True)
+    bits, act, err = r["bits"].cpu().numpy(), r["act"].cpu().numpy(), r["errors"].cpu().numpy()
+    for p_ in range(P):
+        W1, b1, Wo, bo = models[p_]
+        o64 = O.forward(x, [W1, Wo], [b1, bo], np.float64, activation="relu")
+        assert np.abs(act[p_] - o64).max() < 2e-5 * max(1.0, np.abs(o64).max())
+        bad = bits[p_] != O.argmax_first(o64)
+        assert not bad.any() or O.top2_margin(o64)[bad].max() < 1e-4
+        assert err[p_] == int((bits[p_] != labels[p_]).sum())
+    bank.close()
 
 
 @pytest.mark.parametrize("seed", range(10 * SCALE))
