@@ -110,6 +110,16 @@ def load_library() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's):
+    # if this library were loaded first it would pull in the system copy, torch would then load its own, and
+    # the two runtimes do not share a device (measured on the MI355X box: torch.cuda.is_available() turns
+    # False, or nnv_mlp_prepack reports "no gfx950 HIP device").  Importing torch first makes the dynamic
+    # loader resolve our dependency to the copy that is already mapped.  (A torch-free C or ctypes caller,
+    # INTEGRATION.md, uses the system runtime alone and is not affected.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(_LIB_PATH):
         raise NNViterbiError(
             f"{_LIB_PATH} is missing: build it with __graft_entry__.build() "

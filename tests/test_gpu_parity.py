@@ -810,3 +810,18 @@ def test_hip_against_torch_cpu_and_fp64_on_fixtures_and_trained_net(cuda_device,
         flips = cls != tcls
         assert flips.sum() <= max(2, len(x) // 20_000)          # measured: 0-2 per 2 M rows (profiles/r02/flip_rates.json)
         assert not flips.any() or margin[flips].max() < TOL
+
+
+def test_loading_the_library_before_torch_still_leaves_one_hip_runtime(cuda_device):
+    """`import nnviterbi_amd; nnviterbi_amd.load_library()` as the FIRST thing a process does (what
+    __graft_entry__.build() does) must not bring a second HIP runtime into the process: the binding
+    imports torch before it maps libnnviterbi_hip.so.  Run in a fresh interpreter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import nnviterbi_amd; lib = nnviterbi_amd.load_library(); "
+            "import torch; assert torch.cuda.is_available(); assert lib.nnv_device_count() >= 1; "
+            "import __graft_entry__ as g; g.smoke()" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stderr[-2000:]
