@@ -1,0 +1,56 @@
+"""TensorFlow-1.x's CPU tanh, restated: Eigen's ``generic_fast_tanh_float``.
+
+TEST INFRASTRUCTURE ONLY (same rule as ``fnn_oracle.py``).
+
+Why.  The reference's ``tf.nn.tanh`` (src/fnn_viterbi.py:496,500,504,508) runs, on CPU, Eigen's
+``scalar_tanh_op<float>``, which the Eigen snapshot TensorFlow 1.x vendors (``third_party/eigen3``)
+implements as ``internal::generic_fast_tanh_float`` (``Eigen/src/Core/MathFunctionsImpl.h``): clamp
+the argument to [-9, 9], then a 13th-degree odd over 6th-degree even rational function.  It is NOT
+libm's tanh: it is not monotone at the ulp level, it returns values up to 1 + 2^-22, and its steps
+just below 1 sit elsewhere (f(8.5) = 1.0 but f(8.8) = 1 - 2^-24).  So which of two classes within
+~4e-7 of each other TensorFlow's ``argmax`` picks depends on this function's rounding noise: the
+reason the parity contract is a near-tie RULE, and further evidence that the
+forward pass cannot be pinned bit for bit without TensorFlow itself (**parity unpinned**).
+
+The restatement is self-checked (``tests/test_oracle_golden.py``): over [-10, 10] it stays within
+4e-7 of float64 tanh, which a mistyped coefficient would break by orders of magnitude.  TensorFlow's
+pip builds of that era were compiled without FMA, so ``pmadd`` is evaluated as multiply-then-add in
+float32, as here.  The GEMM feeding it (Eigen's blocked sgemm) is NOT restated: its summation order is
+an implementation detail of the build; numpy's float32 matmul stands in (``forward_tf_like``)."""
+from __future__ import annotations
+
+import numpy as np
+
+_F = np.float32
+_ALPHA = [_F(v) for v in (4.89352455891786e-03, 6.37261928875436e-04, 1.48572235717979e-05,
+                          5.12229709037114e-08, -8.60467152213735e-11, 2.00018790482477e-13,
+                          -2.76076847742355e-16)]          # numerator, x^1, x^3, ..., x^13
+_BETA = [_F(v) for v in (4.89352518554385e-03, 2.26843463243900e-03, 1.18534705686654e-04,
+                         1.19825839466702e-06)]            # denominator, x^0, x^2, x^4, x^6
+
+
+def tanh(a):
+    """float32 in, float32 out; every intermediate rounded to float32 (mul, then add)."""
+    x = np.clip(np.asarray(a, dtype=_F), _F(-9.0), _F(9.0))
+    x2 = x * x
+    p = x2 * _ALPHA[6] + _ALPHA[5]
+    for k in (4, 3, 2, 1, 0):
+        p = x2 * p + _ALPHA[k]
+    p = x * p
+    q = x2 * _BETA[3] + _BETA[2]
+    q = x2 * q + _BETA[1]
+    q = x2 * q + _BETA[0]
+    return (p / q).astype(_F)
+
+
+def forward_tf_like(x, weights, biases):
+    """matmul -> add -> Eigen tanh per layer, all float32 (op order of src/fnn_viterbi.py:495-508)."""
+    h = np.asarray(x, dtype=_F)
+    for W, b in zip(weights, biases):
+        h = tanh(np.matmul(h, np.asarray(W, dtype=_F)) + np.asarray(b, dtype=_F))
+    return h
+
+
+def decode(x, weights, biases):
+    out = forward_tf_like(x, weights, biases)
+    return np.argmax(out, axis=1).astype(np.int64), out

@@ -156,8 +156,10 @@ def _triangulate(x, Ws, bs, b):
     c64, _, o64 = O.decode(x, Ws, bs, b, np.float64)
     margin = O.top2_margin(o64)
     c = O.decode_c(x, Ws, bs, b, want_act=True, want_bits=False)
+    from oracle import eigen_tanh as E
     impl = {"numpy_f32": O.decode(x, Ws, bs, b, np.float32)[::2], "c_f32": (c["cls"], c["act"]),
-            "torch_f32": T.decode(x, Ws, bs, torch.float32), "torch_f64": T.decode(x, Ws, bs, torch.float64)}
+            "torch_f32": T.decode(x, Ws, bs, torch.float32), "torch_f64": T.decode(x, Ws, bs, torch.float64),
+            "eigen_tanh_f32": E.decode(x, Ws, bs)}          # TensorFlow-1.x's CPU tanh restated (oracle/eigen_tanh.py)
     for name, (cls, out) in impl.items():
         assert np.abs(out - o64).max() < (1e-12 if name == "torch_f64" else 1e-5), name
         bad = cls != c64
@@ -182,3 +184,18 @@ def test_torch_cpu_triangulates_the_trained_net():
     x, _ = awgn_model.generate("133171", 8, 100_000, O.sigma_from_snr_db(2.0), 20240607, rows_per_block=8)
     flips = _triangulate(x.astype(np.float32), Ws, bs, 8)
     assert max(flips.values()) <= 5          # measured at 2 M rows: <= 2 (profiles/r02/flip_rates.json)
+
+
+def test_eigen_fast_tanh_restatement_self_check():
+    """oracle/eigen_tanh.py restates the rational function TensorFlow 1.x's CPU tanh evaluates (Eigen
+    generic_fast_tanh_float).  Self-check: within 4e-7 of float64 tanh on [-10, 10] (one wrong
+    coefficient digit breaks this by orders of magnitude), exact +-1 beyond the clamp, odd symmetry.
+    And the properties that make near-ties unpinnable: not monotone at the ulp level, overshoots 1.0."""
+    from oracle import eigen_tanh as E
+    xs = np.linspace(-10, 10, 400001).astype(np.float32)
+    e = E.tanh(xs)
+    assert np.abs(e - np.tanh(xs.astype(np.float64))).max() < 4.5e-7
+    assert np.array_equal(E.tanh(-xs), -e)
+    assert E.tanh(np.array([9.0, 30.0, -30.0], np.float32)).tolist() == [1.0, 1.0, -1.0]
+    assert e.max() > 1.0 and (np.diff(e) < 0).sum() > 1000          # overshoot; ulp-level non-monotonicity
+    assert E.tanh(np.array([8.5], np.float32))[0] == 1.0 and E.tanh(np.array([8.8], np.float32))[0] < 1.0

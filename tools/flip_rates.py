@@ -9,6 +9,7 @@ networks (tests/golden/forward_fp64.npz, random weights) and on the trained conf
   c_f32       oracle/fnn_oracle.c   (explicit fmaf chain, libm tanhf)
   torch_f32   oracle/torch_cpu.py   (PyTorch CPU GEMM / tanh / argmax) - the independent one
   torch_f64   the same in float64
+  eigen_tanh_f32  numpy float32 matmul + TensorFlow-1.x's CPU tanh restated (oracle/eigen_tanh.py)
   hip_f32 / hip_f16x3   the product kernel (only with a GPU)
 
 For every implementation: max |out - fp64|, classes differing from fp64, and the largest fp64 top-2
@@ -26,7 +27,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import awgn_model, fnn_oracle as O, torch_cpu as T  # noqa: E402
+from oracle import awgn_model, eigen_tanh as E, fnn_oracle as O, torch_cpu as T  # noqa: E402
 
 import torch  # noqa: E402
 
@@ -41,6 +42,7 @@ def implementations(x, Ws, bs, b, gpu):
     res["c_f32"] = (r["cls"], r["act"])
     res["torch_f32"] = T.decode(x, Ws, bs, torch.float32)
     res["torch_f64"] = T.decode(x, Ws, bs, torch.float64)
+    res["eigen_tanh_f32"] = E.decode(x, Ws, bs)
     if gpu:
         import nnviterbi_amd  # noqa: F401
         from nnviterbi_amd.decoder import PackedMLP
