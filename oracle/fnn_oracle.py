@@ -13,7 +13,9 @@ Parity status
   ``src/fnn_viterbi.py:494-510`` (forward), ``:606-610`` (argmax axis 1),
   ``:648-651`` (MSB-first bits) in numpy, in fp32 (``forward``) and in fp64
   (the arbiter for near-ties), and ``fnn_oracle.c`` restates it again in C
-  with an explicit k-ordered fmaf chain.
+  with an explicit k-ordered fmaf chain.  Further arbiters: ``torch_cpu.py``
+  (PyTorch's CPU kernels, the independent implementation) and ``eigen_tanh.py``
+  (the rational function TensorFlow 1.x's CPU tanh evaluates, restated).
 * numpy half (encoders, channel, codebook, metrics): **pinned** against
   golden vectors generated from the reference itself
   (``tests/golden/reference_numpy_half.*``, ``tests/test_oracle_golden.py``).
