@@ -333,8 +333,12 @@ nnv_status bitwise_launch(const DenseParams &p, hipStream_t stream) {
   if (p.bn != 128 && p.bn != 32) return NNV_ERR_INVALID_ARGUMENT;
   if (!p.bits || !p.head_w || !p.head_b || (p.errors && !p.labels)) return NNV_ERR_INVALID_ARGUMENT;
   const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  // One position (32-column tile, HBM-shaped): 9 KB of unused dynamic LDS caps the kernel at 5 workgroups per
+  // CU instead of 6.  Measured on the reference's default shape (300 k x 1036): 6 per CU 0.306 ms, 5 / 4 / 3 / 2
+  // per CU 0.287 / 0.288 / 0.290 / 0.287 ms (0.54 of the HBM peak): the sixth workgroup only adds contention.
+  constexpr int kCapLds = 9 * 1024;
   if (p.bn == 128) hipLaunchKernelGGL((dense_tanh_kernel<true, 32, 2, 128, true>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((dense_tanh_kernel<true, 32, 2, 32, true>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((dense_tanh_kernel<true, 32, 2, 32, true>), grid, block, kCapLds, stream, p);
   return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 
