@@ -29,19 +29,21 @@ def block_shard(n_blocks: int, rank: int, world_size: int) -> Tuple[int, int]:
     return first, count
 
 
-def init_from_env(backend: Optional[str] = None,
-                  device_index: Optional[int] = None) -> Tuple[int, int, int]:
+def init_from_env(backend: Optional[str] = None, device_index: Optional[int] = None,
+                  force: bool = False) -> Tuple[int, int, int]:
     """Join the process group described by torchrun's environment.
 
     Returns (rank, local_rank, world_size); a no-op for a single process.
     backend: "nccl" (= RCCL on ROCm) when CUDA/HIP is available, else "gloo".
     device_index: the ONE HIP device this rank uses (default LOCAL_RANK); the RCCL group is bound
     to exactly that device, so the caller's allocations and the collective cannot disagree.
+    force: create the group even for WORLD_SIZE == 1 (a one-rank RCCL group: every collective of
+    this module then really goes through RCCL - the only way to execute that branch on a one-GPU box).
     """
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # NNV_DIST_BACKEND=gloo: rehearse the multi-rank path with several ranks on ONE GPU
             backend = os.environ.get("NNV_DIST_BACKEND") or \
@@ -63,7 +65,7 @@ def init_from_env(backend: Optional[str] = None,
 
 def gather_ints(value: int, device=None, group=None) -> list:
     """[value of rank 0, value of rank 1, ...] on every rank (all_gather of one int64)."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not (dist.is_available() and dist.is_initialized()):
         return [int(value)]
     on_host = device is None or dist.get_backend(group) == "gloo"
     t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if on_host else device)
@@ -76,7 +78,7 @@ def all_reduce_counters(counters: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM of an int64 counter tensor over all ranks (any shape)."""
     if counters.dtype != torch.int64:
         raise ValueError("counters must be int64")
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         if counters.is_cuda and dist.get_backend(group) == "gloo":
             host = counters.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
@@ -88,7 +90,7 @@ def all_reduce_counters(counters: torch.Tensor, group=None) -> torch.Tensor:
 
 def max_over_ranks(value: float, device=None, group=None) -> float:
     """MAX all-reduce of a python float (timing)."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not (dist.is_available() and dist.is_initialized()):
         return float(value)
     on_host = device is None or dist.get_backend(group) == "gloo"
     t = torch.tensor([value], dtype=torch.float64, device="cpu" if on_host else device)
@@ -97,7 +99,7 @@ def max_over_ranks(value: float, device=None, group=None) -> float:
 
 
 def barrier(device=None):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         if device is not None and torch.device(device).type == "cuda" and dist.get_backend() != "gloo":
             dist.barrier(device_ids=[torch.device(device).index])
         else:

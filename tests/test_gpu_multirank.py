@@ -63,3 +63,38 @@ def test_bench_two_ranks_rccl(cuda_device):
     one = _bench(1, 2 * BLOCKS)
     assert two["dist_backend"].startswith("rccl") and two["rank_devices"] == [0, 1]
     _check_pair(two, one)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_rccl_branch_with_a_one_rank_group(cuda_device):
+    """The RCCL code path of distributed.py (init_process_group('nccl', device_id=...), int64 SUM
+    all_reduce of device counters, float64 MAX, all_gather, barrier(device_ids=...)) executed for real
+    on the one GPU available: a ONE-rank RCCL group.  It cannot show scaling, but it runs every call
+    the N-rank bench makes through RCCL itself (dtypes, ops, device binding).  Fresh interpreter."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=%r)
+import torch, torch.distributed as dist
+import nnviterbi_amd
+from nnviterbi_amd import distributed as nd
+torch.cuda.set_device(0)
+assert nd.init_from_env(backend="nccl", device_index=0, force=True) == (0, 0, 1)
+assert dist.is_initialized() and dist.get_backend() == "nccl"
+dev = torch.device("cuda", 0)
+c = torch.tensor([[5, 2, 100, 10], [1, 1, 8, 1]], dtype=torch.int64, device=dev)
+assert nd.all_reduce_counters(c).cpu().tolist() == [[5, 2, 100, 10], [1, 1, 8, 1]]
+ones = torch.ones(1, dtype=torch.int64, device=dev); nd.all_reduce_counters(ones); assert int(ones.item()) == 1
+assert nd.max_over_ranks(2.5, device=dev) == 2.5
+assert nd.gather_ints(0, device=dev) == [0]
+nd.barrier(dev)
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl one-rank ok")
+''' % (ROOT, str(29000 + os.getpid() % 2000))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
