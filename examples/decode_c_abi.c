@@ -5,7 +5,9 @@
  * A matched-filter network of the reference's architecture (pass-through hidden layers, class layer =
  * correlation with every codeword of the (133,171) b = 8 tile code, src/fnn_viterbi.py:157-217) decodes
  * blocks generated on the device: at sigma = 0 every block must come back exactly; at 2 dB the BER of
- * the per-tile maximum-likelihood decision is printed.  Exit status 0 = the round trip was exact. */
+ * the per-tile maximum-likelihood decision is printed.  Then the same rows through the HOST entry
+ * (nnv_mlp_decode_host_f32: host arrays in / out), the device rule, and a three-position bit-wise bank.
+ * Exit status 0 = the round trip was exact and every other check held. */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -73,7 +75,64 @@ int main(void) {
            (unsigned long long)host[1], (unsigned long long)host[3]);
     if (pass == 0) exact = host[0] == 0 && host[1] == 0 && host[2] == (uint64_t)n_rows * B && host[3] == (uint64_t)n_rows;
   }
+  /* ---- the reference's own call shape: host rows in, host predictions out (src/fnn_viterbi.py:606-610) ---- */
+  int host_ok = 0;
+  {
+    const int64_t m = 1000 * 1000 + 7;                      /* ragged on purpose */
+    float *xh = malloc((size_t)m * NIN * sizeof(float));
+    int32_t *lh = malloc((size_t)m * sizeof(int32_t)), *dev_cls = malloc((size_t)m * sizeof(int32_t));
+    int64_t *ch = malloc((size_t)m * sizeof(int64_t));
+    uint64_t cnt[4] = {0, 0, 0, 0};
+    CHECK_HIP(hipMemcpy(xh, x, (size_t)m * NIN * sizeof(float), hipMemcpyDeviceToHost));   /* the 2 dB rows of pass 1 */
+    CHECK_HIP(hipMemcpy(lh, labels, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(dev_cls, cls, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+    CHECK_NNV(nnv_mlp_decode_host_f32(h, xh, m, B, lh, NULL, ch, cnt, 100000, 3));
+    int64_t diff = 0;
+    for (int64_t i = 0; i < m; ++i) diff += ch[i] != dev_cls[i];
+    printf("host entry: %lld rows, %lld differ from the resident decode, bit errors %llu / %llu\n", (long long)m,
+           (long long)diff, (unsigned long long)cnt[0], (unsigned long long)cnt[2]);
+    host_ok = diff == 0 && cnt[2] == (uint64_t)m * B && cnt[3] == (uint64_t)m;
+    free(xh); free(lh); free(dev_cls); free(ch);
+  }
+  /* ---- the device rule: a handle is refused on any device but the one it was packed for ---- */
+  int dev = -1;
+  CHECK_HIP(hipGetDevice(&dev));
+  const int rule_ok = nnv_check_device(dev) == NNV_OK && nnv_check_device(dev + 1) == NNV_ERR_INVALID_ARGUMENT;
+  printf("device rule: current device %d ok, device %d refused: %s\n", dev, dev + 1, rule_ok ? "yes" : "NO");
+
+  /* ---- bit-wise decoder bank: 3 positions of a 2(6+10) -> 30 -> 2 ReLU network in one launch
+   *      (src/fnn_viterbi_bitwise.py:326-399,503-505); network p votes bit 1 iff soft value 12 + 2p > 0 ---- */
+  int bank_ok = 0;
+  {
+    enum { K = 32, HID = 30, P = 3, NR = 5000 };
+    float *w1 = calloc(P * K * HID, 4), *bb1 = calloc(P * HID, 4), *wo = calloc(P * HID * 2, 4), *bo = calloc(P * 2, 4);
+    for (int p = 0; p < P; ++p) {
+      w1[(p * K + 12 + 2 * p) * HID + 0] = 1.0f;            /* hidden unit 0 = relu(+x_k) */
+      w1[(p * K + 12 + 2 * p) * HID + 1] = -1.0f;           /* hidden unit 1 = relu(-x_k) */
+      wo[(p * HID + 0) * 2 + 1] = 1.0f;                     /* logit 1 <- unit 0 */
+      wo[(p * HID + 1) * 2 + 0] = 1.0f;                     /* logit 0 <- unit 1 */
+    }
+    nnv_bitwise_desc bd = {K, HID, P, w1, bb1, wo, bo};
+    nnv_bitwise_handle *bh = NULL;
+    CHECK_NNV(nnv_bitwise_prepack(&bd, &bh));
+    float *xs = malloc(NR * K * sizeof(float)), *xd = NULL;
+    uint8_t *bits_d = NULL, *bits_h = malloc(P * NR);
+    for (int i = 0; i < NR * K; ++i) xs[i] = (float)((i * 2654435761u >> 7) % 7) - 3.0f;   /* -3 .. 3, zeros included */
+    CHECK_HIP(hipMalloc((void **)&xd, NR * K * sizeof(float)));
+    CHECK_HIP(hipMalloc((void **)&bits_d, P * NR));
+    CHECK_HIP(hipMemcpy(xd, xs, NR * K * sizeof(float), hipMemcpyHostToDevice));
+    CHECK_NNV(nnv_bitwise_decode_f32(bh, xd, NR, bits_d, NULL, NULL, NULL, NULL));
+    CHECK_HIP(hipMemcpy(bits_h, bits_d, P * NR, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int p = 0; p < P; ++p)
+      for (int r = 0; r < NR; ++r) bad += bits_h[p * NR + r] != (xs[r * K + 12 + 2 * p] > 0.0f);   /* ties at 0 -> bit 0 */
+    printf("bit-wise bank: %d positions x %d rows, %d wrong\n", P, NR, bad);
+    bank_ok = bad == 0;
+    CHECK_NNV(nnv_bitwise_free(bh));
+    hipFree(xd); hipFree(bits_d);
+    free(w1); free(bb1); free(wo); free(bo); free(xs); free(bits_h);
+  }
   CHECK_NNV(nnv_mlp_free(h));
   hipFree(x); hipFree(labels); hipFree(cls); hipFree(counters);
-  return exact ? 0 : 4;
+  return (exact && host_ok && rule_ok && bank_ok) ? 0 : 4;
 }

@@ -1,6 +1,6 @@
 """The C ABI from plain C (examples/decode_c_abi.c): the public header compiles as C11, the program
 links against libnnviterbi_hip.so alone (no Python, no torch), and on an MI355X its noiseless round trip
-over 1 M blocks is exact."""
+over 1 M blocks is exact; the host-array entry, the device rule and the bit-wise bank are exercised from C too."""
 import os
 import shutil
 import subprocess
@@ -38,3 +38,5 @@ def test_c_example_round_trip_is_exact(tmp_path, cuda_device):
     assert lines[0].startswith("sigma 0.0000: bit errors 0 / 64000000") and "tile errors 0 / 8000000" in lines[0]
     ber = float(lines[1].split("BER ")[1].split(")")[0])
     assert 1e-3 < ber < 2e-2          # per-tile ML decision of the (133,171) b = 8 tile code at 2 dB
+    assert "host entry: 1000007 rows, 0 differ from the resident decode" in r.stdout
+    assert "refused: yes" in r.stdout and "bit-wise bank: 3 positions x 5000 rows, 0 wrong" in r.stdout
