@@ -341,3 +341,18 @@ def test_bitwise_numpy_half_matches_reference(golden):
     assert w["out"].shape == (sb.n_hidden_1, 2) and w["h2"].shape == (30, 100) and w["h1"].shape == (36, 30)
     Ws, bs = bw.active_layers(w, b)
     assert [a.shape for a in Ws] == [(36, 30), (30, 2)] and [a.shape for a in bs] == [(30,), (2,)]
+
+
+def test_missing_library_fails_loudly():
+    """No silent fallback when libnnviterbi_hip.so is absent: loading (and hence every compute entry,
+    the torch ops' HIP key included) raises NNViterbiError naming the build command."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import nnviterbi_amd\n"
+            "try:\n    nnviterbi_amd.load_library()\nexcept nnviterbi_amd.NNViterbiError as e:\n"
+            "    print('LOUD:', e)\n" % root)
+    env = dict(os.environ, NNV_LIB="/nonexistent/libnnviterbi_hip.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "LOUD:" in r.stdout and "is missing" in r.stdout and "no CPU fallback" in r.stdout, r.stdout + r.stderr
