@@ -9,6 +9,8 @@
 // (dense_tanh_kernel<.., HEAD> in nnv_dense.hip): every row of x is read once per 4 positions' tile
 // from L2/HBM instead of once per position per launch, the hidden matrix never reaches HBM, and one
 // decided bit per (position, row) is written.  Host side only in this file.
+#include <stdlib.h>
+
 #include <new>
 #include <vector>
 
@@ -101,6 +103,7 @@ int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, 
   nnv::DenseParams p{};
   p.A = x_dev;
   p.a_row_stride = h->n_input;
+  p.a16 = (h->n_input % 4 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 16 == 0) ? 1 : 0;  // bank: 79.0 -> 77.9 ms
   p.n_rows = n_rows;
   p.K = h->n_input;
   p.Kpad = h->kpad;

@@ -90,11 +90,15 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
       int64_t r = row0 + ld_row + kRowsPerPass * ps;
       r = r < p.n_rows ? r : p.n_rows - 1;
       const float *src = p.A + r * p.a_row_stride + k;
-      if (GATHER && (kt + 1) * kBK <= p.K) {  // whole k-tile inside the row: two plain 8-byte loads
-        const f32x2 t0 = *reinterpret_cast<const f32x2 *>(src);
-        const f32x2 t1 = *reinterpret_cast<const f32x2 *>(src + 2);
-        const f32x4 v = {t0[0], t0[1], t1[0], t1[1]};
-        ra[ps] = v;
+      if (GATHER && (kt + 1) * kBK <= p.K) {  // whole k-tile inside the row
+        if (p.a16) {                            // rows 16-byte aligned (matrix rows, K % 4 == 0): one dwordx4
+          ra[ps] = *reinterpret_cast<const f32x4 *>(src);
+        } else {                                // windows of a stream (8-byte aligned): two plain 8-byte loads
+          const f32x2 t0 = *reinterpret_cast<const f32x2 *>(src);
+          const f32x2 t1 = *reinterpret_cast<const f32x2 *>(src + 2);
+          const f32x4 v = {t0[0], t0[1], t1[0], t1[1]};
+          ra[ps] = v;
+        }
       } else if (GATHER) {  // last k-tile: the row ends inside it, guarded loads, zero fill
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (k + 1 < p.K) {

@@ -196,6 +196,7 @@ struct DenseParams {
   const float *A;        // activations [n_rows][a_row_stride] or, gathered, stream + row * a_row_stride
   int64_t a_row_stride;  // floats between consecutive rows
   int64_t n_rows;
+  int32_t a16;           // gather mode: every row start is 16-byte aligned (one dwordx4 per chunk instead of two dwordx2)
   int32_t K;             // valid inputs (gather mode zero-fills k >= K)
   int32_t Kpad;          // multiple of 32; Wt rows have this length
   const float *Wt;       // [Mpad][Kpad] fp32, zero padded

@@ -255,6 +255,7 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev, int64_
       nnv::DenseParams dp{};
       dp.A = in;
       dp.a_row_stride = in_stride;
+      dp.a16 = (l == 0 && in_stride % 4 == 0 && reinterpret_cast<uintptr_t>(in) % 16 == 0) ? 1 : 0;
       dp.n_rows = rows;
       dp.K = h->dims[l];
       dp.Kpad = h->kpad[l];
