@@ -15,8 +15,12 @@ forward pass cannot be pinned bit for bit without TensorFlow itself (**parity un
 The restatement is self-checked (``tests/test_oracle_golden.py``): over [-10, 10] it stays within
 4e-7 of float64 tanh, which a mistyped coefficient would break by orders of magnitude.  TensorFlow's
 pip builds of that era were compiled without FMA, so ``pmadd`` is evaluated as multiply-then-add in
-float32, as here.  The GEMM feeding it (Eigen's blocked sgemm) is NOT restated: its summation order is
-an implementation detail of the build; numpy's float32 matmul stands in (``forward_tf_like``)."""
+float32, as here.  The GEMM feeding it is Eigen's blocked gebp kernel; for depths inside one k-block
+(all of this path's layers) it keeps one accumulator per output and walks k in order, which
+``matmul_seq_k`` restates (product rounded, then added: no FMA); ``forward_tf_like(seq_k=True)`` is the
+closest statement of TensorFlow-1.x's CPU forward pass available without TensorFlow, numpy's BLAS matmul
+(``seq_k=False``) the quick stand-in.  Neither is a pin: thread partitioning, packet width and
+compiler flags of the actual build are not known."""
 from __future__ import annotations
 
 import numpy as np
@@ -43,14 +47,30 @@ def tanh(a):
     return (p / q).astype(_F)
 
 
-def forward_tf_like(x, weights, biases):
-    """matmul -> add -> Eigen tanh per layer, all float32 (op order of src/fnn_viterbi.py:495-508)."""
+def matmul_seq_k(h, W):
+    """C = h W in float32 with ONE accumulator per output, k ascending, every product rounded to
+    float32 and then added (no FMA): the order of Eigen's gebp micro-kernel (TensorFlow's CPU MatMul)
+    when the whole depth fits one k-block (Eigen blocks k at 256 or more; the networks here have
+    K <= 128) in a build without FMA, as TensorFlow 1.x's pip wheels were.  O(K) numpy passes."""
+    h = np.asarray(h, dtype=_F)
+    W = np.asarray(W, dtype=_F)
+    acc = np.zeros((h.shape[0], W.shape[1]), dtype=_F)
+    for k in range(W.shape[0]):
+        acc += h[:, k:k + 1] * W[k:k + 1, :]              # float32 product, float32 add
+    return acc
+
+
+def forward_tf_like(x, weights, biases, seq_k=False):
+    """matmul -> add -> Eigen tanh per layer, all float32 (op order of src/fnn_viterbi.py:495-508).
+    ``seq_k``: the matmul as ``matmul_seq_k`` (closest restatement of TF-1.x's CPU arithmetic we can
+    state) instead of numpy's BLAS call."""
     h = np.asarray(x, dtype=_F)
     for W, b in zip(weights, biases):
-        h = tanh(np.matmul(h, np.asarray(W, dtype=_F)) + np.asarray(b, dtype=_F))
+        z = matmul_seq_k(h, W) if seq_k else np.matmul(h, np.asarray(W, dtype=_F))
+        h = tanh(z + np.asarray(b, dtype=_F))
     return h
 
 
-def decode(x, weights, biases):
-    out = forward_tf_like(x, weights, biases)
+def decode(x, weights, biases, seq_k=False):
+    out = forward_tf_like(x, weights, biases, seq_k=seq_k)
     return np.argmax(out, axis=1).astype(np.int64), out

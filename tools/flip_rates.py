@@ -10,6 +10,7 @@ networks (tests/golden/forward_fp64.npz, random weights) and on the trained conf
   torch_f32   oracle/torch_cpu.py   (PyTorch CPU GEMM / tanh / argmax) - the independent one
   torch_f64   the same in float64
   eigen_tanh_f32  numpy float32 matmul + TensorFlow-1.x's CPU tanh restated (oracle/eigen_tanh.py)
+  tf_like_f32     sequential-k, no-FMA float32 matmul (Eigen gebp order) + that tanh, on the first 300 k rows
   hip_f32 / hip_f16x3   the product kernel (only with a GPU)
 
 For every implementation: max |out - fp64|, classes differing from fp64, and the largest fp64 top-2
@@ -43,6 +44,9 @@ def implementations(x, Ws, bs, b, gpu):
     res["torch_f32"] = T.decode(x, Ws, bs, torch.float32)
     res["torch_f64"] = T.decode(x, Ws, bs, torch.float64)
     res["eigen_tanh_f32"] = E.decode(x, Ws, bs)
+    m = min(len(x), TF_LIKE_ROWS)                      # sequential-k matmul: O(K) numpy passes, on a prefix
+    tcls, tout = E.decode(x[:m], Ws, bs, seq_k=True)
+    res["tf_like_f32"] = (tcls, tout)
     if gpu:
         import nnviterbi_amd  # noqa: F401
         from nnviterbi_amd.decoder import PackedMLP
@@ -56,6 +60,9 @@ def implementations(x, Ws, bs, b, gpu):
     return res
 
 
+TF_LIKE_ROWS = 300_000
+
+
 def table(x, Ws, bs, b, gpu):
     res = implementations(x, Ws, bs, b, gpu)
     c64, o64 = res["fp64"]
@@ -64,14 +71,16 @@ def table(x, Ws, bs, b, gpu):
     per = {}
     for k in names[1:]:
         cls, out = res[k]
-        bad = cls != c64
-        per[k] = {"max_abs_err_vs_fp64": float(np.abs(out - o64).max()),
+        m = len(cls)
+        bad = cls != c64[:m]
+        per[k] = {"rows": int(m), "max_abs_err_vs_fp64": float(np.abs(out - o64[:m]).max()),
                   "classes_differing_from_fp64": int(bad.sum()),
-                  "max_fp64_margin_on_those_rows": float(margin[bad].max()) if bad.any() else 0.0}
+                  "max_fp64_margin_on_those_rows": float(margin[:m][bad].max()) if bad.any() else 0.0}
     pair = {}
     for i, a in enumerate(names):
         for c in names[i + 1:]:
-            pair[f"{a}|{c}"] = int((res[a][0] != res[c][0]).sum())
+            m = min(len(res[a][0]), len(res[c][0]))
+            pair[f"{a}|{c}"] = int((res[a][0][:m] != res[c][0][:m]).sum())
     return {"rows": int(x.shape[0]), "per_implementation": per, "pairwise_class_flips": pair}
 
 
