@@ -49,10 +49,7 @@ nnv_status shape_from_desc(const nnv_mlp_desc *net, int32_t precision, PackedSha
   int mts = s->mt_out;
   for (int i = 0; i < s->nhid; ++i) mts += s->mt[i];
   s->bias_floats = 32LL * mts;
-  // the class layer is streamed when the whole network + the argmax winner slots (64 B x 1024 threads)
-  // do not fit the LDS together
-  const int64_t slots = nnv::kKeepLds ? 1024 * 64 : 0;
-  s->streams = (s->hid_floats + s->out_floats + s->bias_floats) * 4 + nnv::kLdsTailBytes + slots > kLdsLimitBytes ? 1 : 0;
+  // s->streams (resident or ring-swept class layer) is decided with the workgroup size: nnv::decode_configure
   return nnv::decode_supported(*s);
 }
 
@@ -269,25 +266,25 @@ int32_t nnv_mlp_prepack(const nnv_mlp_desc *net, nnv_mlp_handle **out) {
 int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision, nnv_mlp_handle **out) {
   if (!net || !out) return NNV_ERR_INVALID_ARGUMENT;
   *out = nullptr;
-  PackedShape s;
-  const nnv_status st = shape_from_desc(net, precision, &s);
+  PackedShape s0;
+  const nnv_status st = shape_from_desc(net, precision, &s0);
   if (st != NNV_OK) return st;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return NNV_ERR_NO_DEVICE;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NNV_ERR_NO_DEVICE;
   if (!is_gfx950(prop)) return NNV_ERR_NO_DEVICE;
-  if ((s.hid_floats + s.bias_floats) * 4 > kLdsLimitBytes) return NNV_ERR_UNSUPPORTED_SHAPE;
+  if ((s0.hid_floats + s0.bias_floats) * 4 > kLdsLimitBytes) return NNV_ERR_UNSUPPORTED_SHAPE;
 
   std::vector<float> packed;
-  if (s.precision == nnv::kPrecF16x3) {
-    if (!pack_network_f16x3(net, s, &packed)) return NNV_ERR_UNSUPPORTED_SHAPE;  // weight outside f16 range
+  if (s0.precision == nnv::kPrecF16x3) {
+    if (!pack_network_f16x3(net, s0, &packed)) return NNV_ERR_UNSUPPORTED_SHAPE;  // weight outside f16 range
   } else {
-    pack_network(net, s, &packed);
+    pack_network(net, s0, &packed);
   }
   nnv_mlp_handle *h = new (std::nothrow) nnv_mlp_handle;
   if (!h) return NNV_ERR_OUT_OF_MEMORY;
-  h->shape = s;
+  h->shape = s0;
   for (int l = 0; l <= NNV_MAX_LAYERS; ++l) h->dims[l] = l <= net->depth ? net->dims[l] : 0;
   h->wpack_floats = static_cast<int64_t>(packed.size());
   h->device = dev;
@@ -304,7 +301,8 @@ int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision, nnv_mlp_h
     delete h;
     return NNV_ERR_HIP;
   }
-  h->threads = nnv::decode_pick_threads(s);
+  h->threads = nnv::decode_configure(&h->shape, h->lds_limit);
+  const PackedShape &s = h->shape;
   const nnv_status prep = nnv::decode_prepare(s, h->num_cus, h->lds_limit, h->threads, dev);
   h->vgprs = nnv::decode_kernel_vgprs(s, h->threads, s.streams == 0 && s.n_classes % 32 == 0);
   if (prep != NNV_OK) {

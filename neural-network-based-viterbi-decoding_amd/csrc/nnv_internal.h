@@ -145,11 +145,23 @@ constexpr int kVarGeneral = 0, kVarStream = 1, kVarLean = 2;
 #define NNV_KEEP_LDS 1
 #endif
 constexpr bool kDeferArgmax = NNV_DEFER_ARGMAX != 0;
-// General and lean variants (LDS-resident networks): the running argmax winner's 16 raw accumulators are
-// parked in a per-lane LDS slot by exec-masked ds_write_b128 (no VALU) instead of 16 v_cndmask per class
-// tile: 64 bytes per thread, reserved by decode_plan.  The stream variant keeps them in registers
-// (0 = A/B builds: every variant does).
+// The running argmax winner's 16 raw accumulators are parked in a per-lane LDS slot by exec-masked
+// ds_write_b128 (no VALU) instead of 16 v_cndmask per class tile: 64 bytes per thread, reserved by
+// decode_plan (0 = A/B builds: kept in registers).
 constexpr bool kKeepLds = kDeferArgmax && NNV_KEEP_LDS != 0;
+
+// Stream variant: class M-tiles per slot of the two-slot LDS ring (mlp_decode_kernel's RT; decode_plan
+// sizes the ring from the same function).  Slot size in KB per precision; a class tile is 4 kt_out KB.
+#ifndef NNV_RING_KB_F32
+#define NNV_RING_KB_F32 8
+#endif
+#ifndef NNV_RING_KB_F16
+#define NNV_RING_KB_F16 8
+#endif
+constexpr int ring_tiles_per_slot(int prec, int kt_out) {
+  const int kb = prec == kPrecF32 ? NNV_RING_KB_F32 : NNV_RING_KB_F16;
+  return kb / (4 * kt_out) >= 1 ? kb / (4 * kt_out) : 1;
+}
 
 constexpr int kMaxBins = 16;
 constexpr int kLdsTailBytes = 16 + kMaxBins * 16;  // work counter + per-bin {bit, frame, rows, pad}
@@ -182,6 +194,8 @@ nnv_status decode_supported(const PackedShape &s);
 // threads: the workgroup size picked ONCE at prepack (decode_pick_threads) and kept in the handle, so a
 // launch is table lookups + hipLaunchKernel, without runtime attribute queries.
 int decode_pick_threads(const PackedShape &s);
+// decides s->streams (class layer resident or swept through the LDS ring) and returns the workgroup size
+int decode_configure(PackedShape *s, int lds_limit);
 nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
                        int lds_limit, int threads, LaunchPlan *plan);
 nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,

@@ -20,7 +20,10 @@
 //    LDS resident (one copy per CU, shared by all waves of a persistent
 //    workgroup); one ds_read_b128 feeds 4 MFMAs.  Of a class layer too large
 //    for the 160 KiB LDS as many M-tiles as fit stay resident; the rest is
-//    streamed from L2 as one linear, register-double-buffered fragment stream.
+//    swept by the whole workgroup TOGETHER through a two-slot LDS ring that the
+//    waves fill by LDS-DMA (global_load_lds_dwordx4): each streamed fragment
+//    leaves L2 once per workgroup, not once per wave, and every class tile is
+//    consumed from LDS.
 //  * bias (the accumulator's initial value) + tanh (v_exp_f32 / v_rcp_f32) +
 //    first-max argmax on clamped pre-activations run on the VALU.  On gfx950 the
 //    fp32 MFMA shares its pipe with the VALU, so every vector instruction in the
@@ -295,6 +298,19 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   unsigned *bin_ctr = tile_ctr + 4;  // [kMaxBins][4] u32, used only when n_bins > 1
   if (threadIdx.x == 0) *tile_ctr = 0u;
   if (threadIdx.x < kMaxBins * 4) bin_ctr[threadIdx.x] = 0u;
+  // behind them: the argmax winner slots (64 B per thread), then (stream variant) the class-layer ring
+  constexpr bool KEEP_LDS = kKeepLds;
+  float *const keep_base = reinterpret_cast<float *>(bin_ctr + kMaxBins * 4);
+  constexpr int NW = NT / 64;
+  // ---- stream variant: the class-layer ring -------------------------------------------------------
+  // A slot holds RT consecutive class M-tiles (8 KB; 16 KB for KT_OUT = 4) = GPS fragment groups, which
+  // are contiguous in the packed network: one wave-level global_load_lds_dwordx4 moves one 1 KB group
+  // (per-lane source, lane-linear LDS image = the fragment-group layout itself; no VGPRs, no ds_write).
+  constexpr int RT = ring_tiles_per_slot(PREC, KT_OUT);
+  constexpr int GPT = KT_OUT * 4;                    // fragment groups per class tile (both precisions)
+  constexpr int GPS = RT * GPT;                      // groups per ring slot
+  constexpr int SLOT_FLOATS = GPS * kFragGroupFloats;
+  float *const ring = keep_base + (KEEP_LDS ? NT * 16 : 0);
 
   // ---- stage the packed network into LDS (once per persistent workgroup) --
   {
@@ -323,7 +339,36 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     k = __builtin_amdgcn_readfirstlane(k);
     return static_cast<int64_t>(blockIdx.x) + static_cast<int64_t>(k) * gridDim.x;
   };
-  int64_t tile = grab_tile();
+  const int wave = threadIdx.x >> 6;
+  // Stream variant: the waves of a workgroup sweep the streamed class tiles in lock step (one barrier per
+  // ring slot), so tiles are dealt per ROUND instead: in round r wave v takes the workgroup's tile r NW + v
+  // (workgroup w owns tiles w, w + G, ...), every wave runs the same number of rounds and ring phases, and
+  // a wave without a tile in the last round only keeps the ring going (DMA + barriers).
+  int rounds = 0, n_slots = 0, round = 0;
+  int64_t total_phases = 0, phase = 0;
+  int64_t tile;
+  if constexpr (STREAM) {
+    const int64_t mine = static_cast<int64_t>(blockIdx.x) < p.n_tiles ? (p.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    rounds = static_cast<int>((mine + NW - 1) / NW);
+    n_slots = (p.mt_out - p.out_lds_tiles + RT - 1) / RT;
+    total_phases = static_cast<int64_t>(rounds) * n_slots;
+    tile = static_cast<int64_t>(blockIdx.x) + static_cast<int64_t>(wave) * gridDim.x;
+  } else {
+    tile = grab_tile();
+  }
+  // slot `slot_idx` of a round (class tiles out_lds_tiles + slot_idx RT ...) -> ring buffer `buf`
+  auto ring_fill = [&](int slot_idx, int buf) {
+    const int first = (p.out_lds_tiles + slot_idx * RT) * GPT;
+    const int last = p.mt_out * GPT - 1;  // a partial last slot re-reads the last group (valid memory, unused)
+    for (int g = wave; g < GPS; g += NW) {
+      const int gi = first + g < last ? first + g : last;
+      __builtin_amdgcn_global_load_lds(p.wpack + HIDF + static_cast<int64_t>(gi) * kFragGroupFloats + lane * 4,
+                                       ring + buf * SLOT_FLOATS + g * kFragGroupFloats, 16, 0, 0);
+    }
+  };
+  if constexpr (STREAM) {
+    if (total_phases > 0) ring_fill(0, 0);
+  }
 
   unsigned bit_err = 0, frame_err = 0;
   float xr[XN];
@@ -346,8 +391,9 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   unsigned long long diag_tiles = 0;
 #endif
 
-  while (tile < p.n_tiles) {
-    const int64_t next_tile = grab_tile();
+  while (STREAM ? round < rounds : tile < p.n_tiles) {
+    const bool valid = !STREAM || tile < p.n_tiles;  // wave-uniform
+    const int64_t next_tile = STREAM ? tile + static_cast<int64_t>(NW) * gridDim.x : grab_tile();
     float xn[XN];
     // The packed weights in LDS never change, so LLVM would hoist every
     // fragment read out of this persistent loop (and spill them).  Making the
@@ -360,76 +406,78 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     int label = 0;
     if (p.labels && half == 0 && row < p.n_rows) label = p.labels[row];  // needed only in the epilogue
     NNV_STAMP(0);  // loop top / x wait
-    // ---------------- layer 1 (K = n_in), streamed into layer 2 ---------------
-    // Each 32-neuron tile of layer 1 is consumed by layer 2's accumulators as soon
-    // as it exists (k-tile by k-tile), so only ONE layer-1 tile is live at a time:
-    // ~48 fewer registers than holding the whole layer (4 waves/SIMD in f16x3).
-    u32x4 xhi[KS1], xlo[KS1];
-    if constexpr (PREC == kPrecF16x3) {
-#pragma unroll
-      for (int s = 0; s < KS1; ++s) split8(xr + 8 * s, xhi[s], xlo[s]);
-    }
-    auto layer1_tile = [&](int mt) -> f32x16 {
-      f32x16 acc = init_acc(lds + B1OFF + 32 * mt, half);
-      if constexpr (PREC == kPrecF32) {
-#pragma unroll
-        for (int g = 0; g < G1; ++g) {
-          const f32x4 a = load_a(lds + (mt * G1 + g) * kFragGroupFloats + lo);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc = mfma32(a[e], xr[4 * g + e], acc);
-        }
-      } else {
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) {
-          const float *wb = lds + mt * L1_PER_MT + s * 2 * kFragGroupFloats + lo;
-          const u32x4 ahi = *reinterpret_cast<const u32x4 *>(wb);
-          const u32x4 alo = *reinterpret_cast<const u32x4 *>(wb + kFragGroupFloats);
-          acc = mfma16(alo, xhi[s], acc);
-          acc = mfma16(ahi, xlo[s], acc);
-          acc = mfma16(ahi, xhi[s], acc);
-        }
-      }
-      act16<PREC>(acc);
-      return acc;
-    };
     ActTile<PREC> ha[NHID == 1 ? MTA : 1];
     ActTile<PREC> hb[NHID >= 2 ? MTB : 1];
-    if constexpr (NHID == 1) {
-#pragma unroll
-      for (int mt = 0; mt < MTA; ++mt) ha[mt].set(layer1_tile(mt));
-      if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
-      NNV_STAMP(1);
-    } else {
-      f32x16 acc2[MTB];
-#pragma unroll
-      for (int mt = 0; mt < MTB; ++mt) acc2[mt] = init_acc(lds + B2OFF + 32 * mt, half);
-#pragma unroll
-      for (int kt = 0; kt < MTA; ++kt) {
-        ActTile<PREC> a[1];
-        a[0].set(layer1_tile(kt));
-#pragma unroll
-        for (int mt = 0; mt < MTB; ++mt)
-          acc2[mt] = dense_tile<PREC, 1>(a, lds + W1F + (mt * MTA + kt) * 4 * kFragGroupFloats + lo, acc2[mt]);
-      }
-      NNV_STAMP(1);  // layer 1 + layer 2 MFMAs
-      if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
-#pragma unroll
-      for (int mt = 0; mt < MTB; ++mt) {
-        act16<PREC>(acc2[mt]);
-        hb[mt].set(acc2[mt]);
-      }
-    }
-
-    NNV_STAMP(2);  // layer 2
-    // ---------------- layer 3 ---------------------------------------------
     ActTile<PREC> hc[NHID >= 3 ? MTC : 1];
-    if constexpr (NHID >= 3) {
+    if (valid) {
+      // ---------------- layer 1 (K = n_in), streamed into layer 2 ---------------
+      // Each 32-neuron tile of layer 1 is consumed by layer 2's accumulators as soon
+      // as it exists (k-tile by k-tile), so only ONE layer-1 tile is live at a time:
+      // ~48 fewer registers than holding the whole layer (4 waves/SIMD in f16x3).
+      u32x4 xhi[KS1], xlo[KS1];
+      if constexpr (PREC == kPrecF16x3) {
 #pragma unroll
-      for (int mt = 0; mt < MTC; ++mt) {
-        f32x16 acc = init_acc(lds + B3OFF + 32 * mt, half);
-        acc = dense_tile<PREC, MTB>(hb, lds + W1F + W2F + mt * MTB * 4 * kFragGroupFloats + lo, acc);
+        for (int s = 0; s < KS1; ++s) split8(xr + 8 * s, xhi[s], xlo[s]);
+      }
+      auto layer1_tile = [&](int mt) -> f32x16 {
+        f32x16 acc = init_acc(lds + B1OFF + 32 * mt, half);
+        if constexpr (PREC == kPrecF32) {
+#pragma unroll
+          for (int g = 0; g < G1; ++g) {
+            const f32x4 a = load_a(lds + (mt * G1 + g) * kFragGroupFloats + lo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma32(a[e], xr[4 * g + e], acc);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < KS1; ++s) {
+            const float *wb = lds + mt * L1_PER_MT + s * 2 * kFragGroupFloats + lo;
+            const u32x4 ahi = *reinterpret_cast<const u32x4 *>(wb);
+            const u32x4 alo = *reinterpret_cast<const u32x4 *>(wb + kFragGroupFloats);
+            acc = mfma16(alo, xhi[s], acc);
+            acc = mfma16(ahi, xlo[s], acc);
+            acc = mfma16(ahi, xhi[s], acc);
+          }
+        }
         act16<PREC>(acc);
-        hc[mt].set(acc);
+        return acc;
+      };
+      if constexpr (NHID == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MTA; ++mt) ha[mt].set(layer1_tile(mt));
+        if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
+        NNV_STAMP(1);
+      } else {
+        f32x16 acc2[MTB];
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt) acc2[mt] = init_acc(lds + B2OFF + 32 * mt, half);
+#pragma unroll
+        for (int kt = 0; kt < MTA; ++kt) {
+          ActTile<PREC> a[1];
+          a[0].set(layer1_tile(kt));
+#pragma unroll
+          for (int mt = 0; mt < MTB; ++mt)
+            acc2[mt] = dense_tile<PREC, 1>(a, lds + W1F + (mt * MTA + kt) * 4 * kFragGroupFloats + lo, acc2[mt]);
+        }
+        NNV_STAMP(1);  // layer 1 + layer 2 MFMAs
+        if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt) {
+          act16<PREC>(acc2[mt]);
+          hb[mt].set(acc2[mt]);
+        }
+      }
+
+      NNV_STAMP(2);  // layer 2
+      // ---------------- layer 3 ---------------------------------------------
+      if constexpr (NHID >= 3) {
+#pragma unroll
+        for (int mt = 0; mt < MTC; ++mt) {
+          f32x16 acc = init_acc(lds + B3OFF + 32 * mt, half);
+          acc = dense_tile<PREC, MTB>(hb, lds + W1F + W2F + mt * MTB * 4 * kFragGroupFloats + lo, acc);
+          act16<PREC>(acc);
+          hc[mt].set(acc);
+        }
       }
     }
 
@@ -442,35 +490,24 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     }();
     float best = -__builtin_inff();
     int bidx = 0;
-    // Class-layer M-tiles that are not LDS resident are streamed from L2 as one linear sequence of
-    // "units" (fp32: one fragment group = 4 k-steps; f16x3: one k-step's hi + lo groups), double
-    // buffered in registers: unit u + 1 is requested before the MFMAs of unit u issue, across tile
-    // boundaries too, so the L2 latency sits under 4 (3) MFMAs and the tile's argmax instead of in
-    // front of every load (the compiler's own schedule: load, s_waitcnt vmcnt(0), 4 MFMAs).
-    constexpr int UPT = PREC == kPrecF32 ? KT_OUT * 4 : KT_OUT * 2;  // units per tile (even)
-    constexpr int UNIT_FLOATS = PREC == kPrecF32 ? kFragGroupFloats : 2 * kFragGroupFloats;
-    u32x4 ubuf[STREAM ? 2 : 1][PREC == kPrecF32 ? 1 : 2];
-    auto load_unit = [&](int u, int slot) {
-      const int n_units = p.mt_out * UPT;
-      u = u < n_units ? u : n_units - 1;
-      const u32x4 *src = reinterpret_cast<const u32x4 *>(p.wpack + HIDF + lo + static_cast<int64_t>(u) * UNIT_FLOATS);
-      ubuf[slot][0] = src[0];
-      if constexpr (PREC != kPrecF32) ubuf[slot][1] = src[kFragGroupFloats / 4];
-    };
     // Running first maximum over the class tiles, index scan DEFERRED to the end of the row tile.
-    // Per class tile (~28 VALU ops): the tile maximum by a v_max3 tree on the RAW pre-activations,
+    // Per class tile (~12 VALU ops): the tile maximum by a v_max3 tree on the RAW pre-activations,
     // clamped once (clamping is monotone: clamp(max z) == max clamp(z)); strict > against the
-    // earlier M-tiles (lower class indices keep ties); the winner's 16 raw accumulators and its
-    // tile id are kept by conditional moves.  Once per row tile (epilogue, ~40 ops): the smallest
-    // register index r of the kept tile with z_r >= best (equivalent to clamp(z_r) == best because
-    // best <= +sat; if every class sits below -sat nothing matches and the tile's first class
+    // earlier M-tiles (lower class indices keep ties); the winner's 16 raw accumulators are parked
+    // in the lane's LDS slot by exec-masked ds_write_b128 (the LDS port, not the vector ALU the fp32
+    // MFMA occupies), its tile id kept by one conditional move.  Once per row tile (epilogue, ~40 ops):
+    // the smallest register index r of the kept tile with z_r >= best (equivalent to clamp(z_r) == best
+    // because best <= +sat; if every class sits below -sat nothing matches and the tile's first class
     // stands for the all-equal tile), by a descending select scan.  The scan used to run in every
     // class tile (51 ops x 8 tiles; -DNNV_DEFER_ARGMAX=0 restores that for A/B builds).
+    // The update test is "not (m <= best)" rather than "m > best": identical for ordered values, and a
+    // NaN maximum (a row of non-finite soft bits) then ALWAYS parks its tile, whatever v_med3 makes of a
+    // NaN, so the deferred scan can never read a slot an earlier row tile left behind: the decoded class
+    // of such a row is unspecified but a function of that row alone.
     f32x16 keep;
     int btile = 0;
-    constexpr bool KEEP_LDS = !STREAM && kKeepLds;
     // [wave][q][lane][4 floats]: consecutive lanes write consecutive 16-byte pieces (conflict free)
-    float *const keep_slot = reinterpret_cast<float *>(bin_ctr + kMaxBins * 4) + (threadIdx.x >> 6) * 1024 + lane * 4;
+    float *const keep_slot = keep_base + wave * 1024 + lane * 4;
     auto scan_first = [&](const f32x16 &acc, float m) -> unsigned {
       unsigned t = 16u;
 #pragma unroll
@@ -482,7 +519,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #pragma unroll
       for (int r = 2; r < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, acc[r]), acc[r + 1]);
       m = __builtin_amdgcn_fmed3f(m, -kTanhSat, kTanhSat);
-      const bool c = m > best;
+      const bool c = !(m <= best);
       best = c ? m : best;
       if constexpr (KEEP_LDS) {
         btile = c ? mt : btile;
@@ -502,45 +539,8 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         bidx = c ? 32 * mt + 4 * half + 8 * static_cast<int>(t >> 2) + static_cast<int>(t & 3u) : bidx;
       }
     };
-    int mt0 = 0;
-    if constexpr (LEAN) {
-      // two class tiles per iteration: the second tile's MFMAs are independent of the first
-      // tile's argmax, so the scheduler can issue them around it (in f16x3 the matrix pipe
-      // then works under the argmax VALU stream instead of before it)
-      constexpr int kGroup = NNV_CLASS_GROUP;
-      for (; mt0 + kGroup - 1 < p.mt_out; mt0 += kGroup) {
-        f32x16 accs[kGroup];
-#pragma unroll
-        for (int i = 0; i < kGroup; ++i) {
-          accs[i] = init_acc(lds + BOOFF + 32 * (mt0 + i), half);
-          accs[i] = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + (mt0 + i) * KT_OUT * 4 * kFragGroupFloats + lo, accs[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < kGroup; ++i) argmax_tile(accs[i], mt0 + i);
-      }
-    }
-    if constexpr (STREAM) {
-      if (p.out_lds_tiles < p.mt_out) load_unit(p.out_lds_tiles * UPT, 0);
-    }
-    for (int mt = mt0; mt < p.mt_out; ++mt) {
-      f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
-      if (!STREAM || mt < p.out_lds_tiles) {
-        acc = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + mt * KT_OUT * 4 * kFragGroupFloats + lo, acc);
-      } else if constexpr (STREAM) {
-#pragma unroll
-        for (int j = 0; j < UPT; ++j) {
-          load_unit(mt * UPT + j + 1, (j + 1) & 1);
-          if constexpr (PREC == kPrecF32) {
-            const f32x4 a = __builtin_bit_cast(f32x4, ubuf[j & 1][0]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma32(a[e], hlast[j / 4].v[4 * (j % 4) + e], acc);
-          } else {
-            acc = mfma16(ubuf[j & 1][1], hlast[j / 2].hi[j % 2], acc);  // small terms first
-            acc = mfma16(ubuf[j & 1][0], hlast[j / 2].lo[j % 2], acc);
-            acc = mfma16(ubuf[j & 1][0], hlast[j / 2].hi[j % 2], acc);
-          }
-        }
-      }
+    // what follows a class tile's MFMAs: debug activations, masking of a ragged class count, argmax
+    auto finish_class_tile = [&](f32x16 &acc, int mt) {
       const int cbase = 32 * mt + 4 * half;
       if constexpr (WRITE_ACT) {
         if (row < p.n_rows) {
@@ -559,6 +559,63 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         }
       }
       argmax_tile(acc, mt);
+    };
+    int mt0 = 0;
+    if constexpr (LEAN) {
+      // two class tiles per iteration: the second tile's MFMAs are independent of the first
+      // tile's argmax, so the scheduler can issue them around it (in f16x3 the matrix pipe
+      // then works under the argmax VALU stream instead of before it)
+      constexpr int kGroup = NNV_CLASS_GROUP;
+      for (; mt0 + kGroup - 1 < p.mt_out; mt0 += kGroup) {
+        f32x16 accs[kGroup];
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i) {
+          accs[i] = init_acc(lds + BOOFF + 32 * (mt0 + i), half);
+          accs[i] = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + (mt0 + i) * KT_OUT * 4 * kFragGroupFloats + lo, accs[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i) argmax_tile(accs[i], mt0 + i);
+      }
+    }
+    // LDS-resident class tiles (all of them unless this is the stream variant)
+    if (valid) {
+      const int mt_res = STREAM ? p.out_lds_tiles : p.mt_out;
+      for (int mt = mt0; mt < mt_res; ++mt) {
+        f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
+        acc = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + mt * KT_OUT * 4 * kFragGroupFloats + lo, acc);
+        finish_class_tile(acc, mt);
+      }
+    }
+    // Stream variant: the remaining class tiles, swept by all waves of the workgroup TOGETHER through
+    // the two-slot LDS ring.  Phase s (global count over rounds): barrier -- the DMA of slot s, issued
+    // one whole phase earlier, has landed in buffer s & 1 for every wave (__syncthreads waits vmcnt(0)
+    // first) and nobody still reads buffer (s + 1) & 1 --, then the DMA of slot s + 1 into that buffer,
+    // then RT class tiles of MFMAs from buffer s & 1.  Each streamed fragment leaves L2 once per
+    // workgroup and round (round 2: once per WAVE, 152 KB per row tile of configs[1], with a prefetch
+    // distance of 4 MFMAs) and every class tile is consumed from LDS, the path that sustains 64
+    // cycles per MFMA.
+    if constexpr (STREAM) {
+      for (int i = 0; i < n_slots; ++i) {
+        NNV_STAMP(4);  // resident class tiles / previous slot's MFMAs + argmax
+        __syncthreads();
+        NNV_STAMP(6);  // barrier (incl. the wait for this wave's DMA)
+        ++phase;
+        if (phase < total_phases) ring_fill(i + 1 == n_slots ? 0 : i + 1, static_cast<int>(phase & 1));
+        if (valid) {
+          const float *slot = ring + static_cast<int>((phase - 1) & 1) * SLOT_FLOATS + lo;
+          const int mtb = p.out_lds_tiles + i * RT;
+          f32x16 accs[RT];
+#pragma unroll
+          for (int t = 0; t < RT; ++t) {
+            const int mt = mtb + t < p.mt_out ? mtb + t : p.mt_out - 1;
+            accs[t] = init_acc(lds + BOOFF + 32 * mt, half);
+            accs[t] = dense_tile<PREC, KT_OUT>(hlast, slot + t * GPT * kFragGroupFloats, accs[t]);
+          }
+#pragma unroll
+          for (int t = 0; t < RT; ++t)
+            if (mtb + t < p.mt_out) finish_class_tile(accs[t], mtb + t);
+        }
+      }
     }
     if constexpr (KEEP_LDS) {
 #pragma unroll
@@ -579,11 +636,14 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     // it fp32 tanh has WIDE flat steps (z in [8.32, 9.01) all give 1 - 2^-24, [7.97, 8.32) 1 - 2^-23 ...):
     // the reference's argmax over the tanh'd outputs then returns the LOWEST tied index, the clamped
     // pre-activations the largest z.  Such rows (none in 80 M at 2 dB with the trained network: max z
-    // 4.4) take this wave-uniform cold path: the class layer once more, weights from global memory,
-    // first maximum over tanh_f32(z) -- the very values nnv_mlp_forward_f32 writes, so decode ==
-    // argmax_first(forward) there, as in the layer-at-a-time path (row_argmax_kernel) and the oracle.
+    // 4.4) take this cold path: the class layer once more, weights from global memory, first maximum
+    // over tanh_f32(z) -- the very values nnv_mlp_forward_f32 writes, so decode == argmax_first(forward)
+    // there, as in the layer-at-a-time path (row_argmax_kernel) and the oracle.  The path is ENTERED per
+    // wave (a branch must be wave-uniform) but its result is TAKEN per row: only by rows whose own winner
+    // -- in either lane half, because the half merge below compares like with like -- reached the band.
+    // decode(row) is a function of the row alone, whatever shares its 32-row tile.
     if constexpr (kFlatTopPath) {
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(best >= kFlatBand) != 0, 0)) {
+      if (valid && __builtin_expect(__builtin_amdgcn_ballot_w64(best >= kFlatBand) != 0, 0)) {
         float tb = -__builtin_inff();
         int ti = 0;
         for (int mt = 0; mt < p.mt_out; ++mt) {
@@ -598,8 +658,10 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
             ti = c ? ci : ti;
           }
         }
-        best = tb;
-        bidx = ti;
+        const float other = __shfl_xor(best, 32);  // unconditionally: every lane must take part in the exchange
+        const bool flat = best >= kFlatBand || other >= kFlatBand;
+        best = flat ? tb : best;
+        bidx = flat ? ti : bidx;
       }
     }
 
@@ -611,7 +673,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       const bool take = (ov > best) || (ov == best && oi < bidx);
       bidx = take ? oi : bidx;
     }
-    if (half == 0 && row < p.n_rows) {
+    if (valid && half == 0 && row < p.n_rows) {
       if (p.cls32) p.cls32[row] = bidx;
       if (!LEAN && p.cls64) p.cls64[row] = bidx;
       if (!LEAN && p.bits) {
@@ -638,6 +700,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       for (int s = 0; s < 4 * G1; ++s) xr[s] = xn[s];
     }
     tile = next_tile;
+    ++round;
     NNV_STAMP(5);  // epilogue
 #ifdef NNV_DIAG
     ++diag_tiles;

@@ -58,6 +58,13 @@ int pick_threads_impl(const PackedShape &s) {
   return 512;
 }
 
+
+int64_t keep_slot_bytes(int threads) { return kKeepLds ? static_cast<int64_t>(threads) * 64 : 0; }
+// two ring slots of RT class tiles each; must match RT / GPS / SLOT_FLOATS in mlp_decode_kernel
+int64_t ring_bytes(const PackedShape &s) {
+  return 2LL * ring_tiles_per_slot(s.precision, s.kt_out) * s.kt_out * 4 * kFragGroupFloats * 4;
+}
+
 }  // namespace
 
 nnv_status decode_supported(const PackedShape &s) {
@@ -74,21 +81,35 @@ int decode_kernel_vgprs(const PackedShape &s, int threads, bool lean) {
   return attr.numRegs;
 }
 
+// Resident or streamed?  The whole network stays in LDS (general / lean variants) iff it fits beside the
+// argmax winner slots of the workgroup size that variant runs at; otherwise the class layer is swept
+// through the LDS ring (stream variant).  The workgroup size is picked first, per variant, so a network
+// that fits at 512 threads is not demoted because it would not fit at 1024.
+int decode_configure(PackedShape *s, int lds_limit) {
+  const int64_t whole = (s->hid_floats + s->out_floats + s->bias_floats) * 4 + kLdsTailBytes;
+  s->streams = 0;
+  const int t = pick_threads_impl(*s);
+  if (whole + keep_slot_bytes(t) <= lds_limit) return t;
+  s->streams = 1;
+  return pick_threads_impl(*s);
+}
+
 nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
                        int lds_limit, int threads, LaunchPlan *plan) {
   if (!find_kernel(s, 512, false)) return NNV_ERR_UNSUPPORTED_SHAPE;
   const int64_t base_floats = s.hid_floats + s.bias_floats;
-  // Resident networks (general / lean variants) park the running argmax winner's accumulators in LDS, 64
-  // bytes per thread (shape_from_desc made the network a streaming one if they do not fit beside it).  The
-  // stream variant keeps the winner in registers: its LDS is better spent on class-layer tiles (configs[1],
-  // same-box A/B: 80.1 M blocks/s with 13 of 32 tiles resident, 76-78 M with the slots and 5-9 tiles).
-  const int64_t scratch = (kKeepLds && s.streams == 0) ? static_cast<int64_t>(threads) * 64 : 0;
+  // Every variant parks the running argmax winner's accumulators in LDS, 64 bytes per thread.  The stream
+  // variant adds the two-slot class-layer ring (8 KB slots, 16 KB for 128-wide last hidden layers): with
+  // the ring a streamed class tile costs one barrier per slot and one DMA, so residency matters little and
+  // the LDS is better spent on the slots than on more resident class tiles (round 2, per-wave streaming,
+  // had it the other way round: 13 of 32 tiles resident, winner kept by 16 v_cndmask per class tile).
+  const int64_t scratch = keep_slot_bytes(threads) + (s.streams ? ring_bytes(s) : 0);
   if (base_floats * 4 + kLdsTailBytes + scratch > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
-  // as many class-layer M-tiles as fit stay in LDS; the remaining ones are streamed from L2 per tile
+  // as many class-layer M-tiles as fit stay in LDS; the remaining ones go through the ring
   const int64_t per_tile_bytes = static_cast<int64_t>(s.kt_out) * 4 * kFragGroupFloats * 4;
   int64_t fit = (lds_limit - kLdsTailBytes - scratch - base_floats * 4) / per_tile_bytes;
   if (fit > s.mt_out) fit = s.mt_out;
-  if (s.streams == 0 && fit < s.mt_out) return NNV_ERR_UNSUPPORTED_SHAPE;  // shape_from_desc sized it without the slots
+  if (s.streams == 0 && fit < s.mt_out) return NNV_ERR_UNSUPPORTED_SHAPE;  // decode_configure sized it
   plan->out_lds_tiles = static_cast<int32_t>(fit);
   plan->out_in_lds = fit == s.mt_out ? 1 : 0;
   plan->lds_bytes = static_cast<int32_t>(base_floats * 4 + fit * per_tile_bytes + kLdsTailBytes + scratch);

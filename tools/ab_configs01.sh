@@ -1,0 +1,12 @@
+#!/bin/bash
+# Usage: tools/ab_configs01.sh lib1.so lib2.so ...   (paths relative to the package dir)
+# BASELINE configs[0]/[1] (the K1 stream variant) with each library: ms per launch + fraction of peak.
+for lib in "$@"; do
+  NNV_LIB="$PWD/neural-network-based-viterbi-decoding_amd/$lib" python tools/bench_configs01.py --steps 10 > /tmp/abc.json 2>/tmp/abc.err || tail -5 /tmp/abc.err
+  python - "$lib" <<'PY'
+import json,sys
+for line in open("/tmp/abc.json"):
+    d=json.loads(line)
+    print(f"{sys.argv[1]:22s} {d['config']} f32 {d['f32']['ms_per_launch']:.4f} ms frac {d['f32']['frac_of_peak']:.4f} lds_tiles {d['f32']['class_tiles_in_lds']} | f16x3 {d['f16x3']['ms_per_launch']:.4f} ms {d['f16x3']['value']/1e6:.1f} Mblk/s lds_tiles {d['f16x3']['class_tiles_in_lds']}")
+PY
+done

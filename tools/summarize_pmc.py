@@ -39,6 +39,54 @@ if len(sys.argv) > 1 and sys.argv[1] == "--secondary":
     print("wrote", out_path)
     sys.exit(0)
 
+if len(sys.argv) > 1 and sys.argv[1] == "--stream":
+    # K1 stream variant under tools/bench_configs01.py (tools/profile_stream.sh): per kernel instantiation,
+    # full-size launches only (configs[1]: 10 M rows on 256 workgroups; configs[0] is one 63-workgroup launch)
+    root = sys.argv[2]
+    out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "pmc_stream.json")
+    acc3 = defaultdict(lambda: defaultdict(list))
+    for path in glob.glob(os.path.join(root, "pmc3_*", "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for r in csv.DictReader(f):
+                name = r["Kernel_Name"]
+                if "mlp_decode_kernel" not in name or int(r["Grid_Size"]) < 200 * 512:
+                    continue
+                acc3[name.replace("void nnv::", "").split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    ROWS1 = 10_000_000
+    res = {"source_dir": root, "rows_per_launch": ROWS1, "tiles_per_launch": ROWS1 // 32,
+           "note": "BASELINE configs[1] (20-128-64-1024, 1 M blocks = 10 M rows), per-launch means; FETCH_SIZE/WRITE_SIZE in KB "
+                   "(FETCH_SIZE x2 for wide coalesced streams on gfx950); GRBM_GUI_ACTIVE is summed over 8 XCDs; "
+                   "TCP_TCC_READ_REQ = vector-memory read requests that left the CUs' L1s for L2", "kernels": {}}
+    for name, ctrs in sorted(acc3.items()):
+        k = {n: {"per_launch_mean": sum(v) / len(v), "launches": len(v)} for n, v in sorted(ctrs.items())}
+        g = lambda n: k.get(n, {}).get("per_launch_mean")
+        d = {"counters": k}
+        tiles = ROWS1 // 32
+        if g("SQ_INSTS_VALU") is not None:
+            d["valu_insts_per_tile_incl_mfma"] = g("SQ_INSTS_VALU") / tiles
+            d["mfma_insts_per_tile"] = g("SQ_INSTS_MFMA") / tiles
+        if g("GRBM_GUI_ACTIVE"):
+            d["kernel_cycles_per_xcd"] = g("GRBM_GUI_ACTIVE") / 8
+            d["cycles_per_tile_per_simd"] = d["kernel_cycles_per_xcd"] / (tiles / 1024)
+        if g("FETCH_SIZE") is not None:
+            d["hbm_read_bytes_per_launch_x2_corrected"] = g("FETCH_SIZE") * 2048
+        if g("WRITE_SIZE") is not None:
+            d["hbm_write_bytes_per_launch"] = g("WRITE_SIZE") * 1024
+        if g("TCP_TCC_READ_REQ_sum") is not None:
+            d["l1_to_l2_read_requests_per_tile"] = g("TCP_TCC_READ_REQ_sum") / tiles
+        if g("SQ_WAIT_INST_ANY") is not None and g("SQ_WAVE_CYCLES"):
+            d["wait_inst_any_frac_of_wave_cycles"] = g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")
+        res["kernels"][name] = d
+    # mfma busy needs counters from two passes of the same kernel
+    for name, d in res["kernels"].items():
+        c = d["counters"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+            d["mfma_busy_frac_per_simd"] = c["SQ_VALU_MFMA_BUSY_CYCLES"]["per_launch_mean"] / 1024 / (c["GRBM_GUI_ACTIVE"]["per_launch_mean"] / 8)
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+    print("wrote", out_path)
+    sys.exit(0)
+
 root = sys.argv[1]
 out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "pmc_summary.json")
 ROWS = 80_000_000
