@@ -36,11 +36,14 @@ tiles is.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -54,6 +57,7 @@ from nnviterbi_amd import distributed as nd  # noqa: E402
 from nnviterbi_amd import fnn_viterbi as fv  # noqa: E402
 from nnviterbi_amd.decoder import PackedMLP, generate_awgn_blocks  # noqa: E402
 
+BASELINE_BLOCKS_PER_GPU = 10_000_000   # BASELINE.json configs[2]
 BLOCK_LEN = 64
 TILE_BITS = 8                      # b: largest divisor of 64 that is <= 10
 ROWS_PER_BLOCK = BLOCK_LEN // TILE_BITS
@@ -133,22 +137,116 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def launch_ranks(n_ranks: int) -> int:
+# K1's sources: profiles/pmc_traffic.json records their hash, so a replayed HBM-traffic figure cannot
+# outlive the kernel it was measured on
+K1_SOURCES = ("nnv_mlp_decode.hip", "nnv_mlp_launch.hip", "nnv_internal.h")
+
+
+def k1_source_hash() -> str:
+    h = hashlib.sha1()
+    for name in K1_SOURCES:
+        with open(os.path.join(ROOT, "neural-network-based-viterbi-decoding_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def workload_label(blocks_per_gpu: int, dims) -> str:
+    """`config.workload`, built from what actually ran; a run that is not BASELINE's 10 M blocks per
+    GPU says so in its first word."""
+    if blocks_per_gpu % 1_000_000 == 0:
+        size = f"{blocks_per_gpu // 1_000_000}M"
+    else:
+        size = f"{blocks_per_gpu:,}"
+    text = (f"BASELINE configs[2]: (133,171) K=7, block_len={BLOCK_LEN} as {ROWS_PER_BLOCK} tiles of b={TILE_BITS}, "
+            f"{size} blocks/GPU @ SNR {SNR_DB:g} dB, {len(dims) - 2}-layer FNN {'-'.join(str(d) for d in dims)}")
+    if blocks_per_gpu != BASELINE_BLOCKS_PER_GPU:
+        text = f"REDUCED: not BASELINE's {BASELINE_BLOCKS_PER_GPU // 1_000_000}M blocks/GPU -- " + text
+    return text
+
+
+def replayed_traffic(n_rows: int):
+    """(traffic, traffic_source).  HBM bytes per launch are NOT measured in this run (PMC counters need
+    their own rocprofv3 passes): the figure of the committed profile is replayed, and only while that
+    profile was taken on THIS kernel source and launch size; otherwise null with the reason."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath):
+        return None, "no profiles/pmc_traffic.json"
+    with open(tpath) as f:
+        tj = json.load(f)
+    if tj.get("rows_per_launch") != n_rows:
+        return None, f"profiles/pmc_traffic.json is for {tj.get('rows_per_launch')} rows per launch, this run has {n_rows}"
+    if tj.get("k1_source_sha1") != k1_source_hash():
+        return None, "profiles/pmc_traffic.json is stale: K1's sources changed since its PMC passes"
+    return tj.get("hbm_bytes_per_launch"), (f"replayed from profiles/pmc_traffic.json (rocprofv3 --pmc passes of "
+                                              f"{tj.get('source', '?')}, K1 sources sha1 {tj['k1_source_sha1'][:12]}), "
+                                              f"not measured in this run")
+
+
+def _stage(name: str) -> None:
+    """Rank-side breadcrumb for the launching parent: which rank got how far (read only on a time-out)."""
+    d = os.environ.get("NNV_BENCH_STAGE_DIR")
+    if d:
+        try:
+            with open(os.path.join(d, f"rank{os.environ.get('RANK', '0')}"), "w") as f:
+                f.write(name)
+        except OSError:
+            pass
+
+
+def launch_ranks(n_ranks: int, timeout_s: float, argv=None, script=None) -> int:
     """`python bench.py --gpus N` without a torchrun environment: start the ranks ourselves.
 
     Runs `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a child
     process and returns its exit code.  Called before this process has made any HIP /
     torch.cuda call (a process that has initialised the GPU must never exec or fork GPU work), and
-    it is a plain child, not an exec."""
+    it is a plain child, not an exec.  The child gets `timeout_s` (--launch-timeout, default 300 s): past
+    it the launcher's own process group is terminated (the exact group started here), the stage every
+    rank had reached is printed, and the exit code is 4 -- a stuck rendezvous must end with a diagnosis
+    and without a JSON line, not as a kill at somebody else's limit."""
+    argv = sys.argv[1:] if argv is None else argv
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(_free_port()), script or os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this host driver
+    # dmabuf IPC: this pool's host driver needs HSA_ENABLE_IPC_MODE_LEGACY=0 for RCCL between processes.
+    # The image exports it already; it is set here only when absent, and NNV_KEEP_IPC_ENV=1 leaves the
+    # environment alone altogether (untested between >= 2 GPUs: no multi-GPU box was available to this build).
+    if env.get("NNV_KEEP_IPC_ENV") != "1":
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["NNV_BENCH_LAUNCHED"] = "1"
-    print(f"bench.py: no torchrun environment, launching {n_ranks} ranks: {' '.join(cmd)}",
+    stage_dir = tempfile.mkdtemp(prefix="nnv_bench_stage_")
+    env["NNV_BENCH_STAGE_DIR"] = stage_dir
+    print(f"bench.py: no torchrun environment, launching {n_ranks} ranks (time limit {timeout_s:g} s): {' '.join(cmd)}",
           file=sys.stderr, flush=True)
-    return subprocess.call(cmd, env=env)
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)   # its own process group: killable as a unit
+    try:
+        rc = child.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        stages = {}
+        for r in range(n_ranks):
+            try:
+                with open(os.path.join(stage_dir, f"rank{r}")) as f:
+                    stages[r] = f.read()
+            except OSError:
+                stages[r] = "never started"
+        print(f"bench.py: the {n_ranks}-rank run did not finish within {timeout_s:g} s; stage reached per rank: "
+              f"{stages}; terminating the launcher (pid {child.pid}) and its ranks", file=sys.stderr, flush=True)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)          # the group created above, nothing else
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = 4
+    finally:
+        for name in os.listdir(stage_dir):
+            os.unlink(os.path.join(stage_dir, name))
+        os.rmdir(stage_dir)
+    return rc
 
 
 def main():
@@ -156,7 +254,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--blocks-per-gpu", type=int, default=BASELINE_BLOCKS_PER_GPU)
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("NNV_LAUNCH_TIMEOUT_S", "300")),
+                    help="bare `--gpus N` only: seconds the self-launched ranks get before they are terminated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=("f32", "f16x3"), default="f32",
                     help="f32: exact fp32 MFMA chain (headline, parity reference); "
@@ -164,8 +264,9 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus))       # nothing above touched the GPU
+        sys.exit(launch_ranks(args.gpus, args.launch_timeout))       # nothing above touched the GPU
 
+    _stage("started")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,21 +279,29 @@ def main():
     if n_dev == 0 or not torch.cuda.is_available():
         print(f"bench.py rank {rank}/{world}: needs an MI355X (no CPU fallback for the decode path)",
               file=sys.stderr, flush=True)
-        sys.exit(3)
+        sys.exit(6)    # not 3: gpurun's own "no box free" verdict must stay distinguishable (tools/gpurun_retry.sh)
     if backend == "nccl" and world > n_dev:
         print(f"bench.py rank {rank}/{world}: {world} ranks but {n_dev} GPUs visible (RCCL needs one GPU "
               f"per rank; NNV_DIST_BACKEND=gloo rehearses the N-rank path on fewer)", file=sys.stderr, flush=True)
-        sys.exit(3)
+        sys.exit(6)
     # ONE device index per rank, used for set_device, the process group and every allocation
     dev_index = local_rank % n_dev               # == local_rank except in a gloo rehearsal on fewer GPUs
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    _stage("joining the process group")
     nd.init_from_env(backend=backend if world > 1 else None, device_index=dev_index)
+    _stage("process group up")
     # proof that the collective spans N ranks: SUM of ones over the data path's own backend
     ones = torch.ones(1, dtype=torch.int64, device=dev)
     nd.all_reduce_counters(ones)
     ranks_seen = int(ones.item())
     devices = nd.gather_ints(dev_index, device=dev)
+    try:        # before any timing: N ranks, and under RCCL N distinct GPUs, or no value at all
+        nd.validate_group(ranks_seen, devices, world, require_distinct_devices=(backend == "nccl" and world > 1))
+    except RuntimeError as e:
+        print(f"bench.py rank {rank}/{world}: {e}", file=sys.stderr, flush=True)
+        sys.exit(5)
+    _stage("first collective done")
 
     # ---- network: seeded initialisation of the reference architecture ----
     cfg = fv.DecoderConfig(block_length=TILE_BITS, snr_db=SNR_DB)
@@ -232,8 +341,11 @@ def main():
     torch.cuda.synchronize(dev)
     nd.barrier(dev)
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [e * 1e3 / args.steps for e in nd.gather_floats(elapsed, device=dev)]   # a straggler shows here
+    per_rank_kernel_ms = [k / args.steps for k in nd.gather_floats(kernel_ms, device=dev)]
     elapsed = nd.max_over_ranks(elapsed, device=dev)
     kernel_ms = nd.max_over_ranks(kernel_ms, device=dev)
+    _stage("timed region done")
 
     total = counters.clone()
     nd.all_reduce_counters(total)          # the path's one collective (RCCL)
@@ -268,13 +380,7 @@ def main():
         flop_row, bytes_row = algorithmic_work(dims)
         launch_s = kernel_ms / 1e3 / args.steps
         achieved = flop_row * n_rows / launch_s / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("rows_per_launch") == n_rows:
-                traffic = tj.get("hbm_bytes_per_launch")
+        traffic, traffic_source = replayed_traffic(n_rows) if args.precision == "f32" else (None, "f32 profile only")
         out = {
             "metric": "decoded blocks/sec, (133,171) block_len=64 @ SNR 2 dB",
             "value": world * n_blocks * args.steps / elapsed,
@@ -283,11 +389,11 @@ def main():
             "dist_backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else None),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
+            "ms_per_step_per_rank": per_rank_ms, "kernel_ms_per_launch_per_rank": per_rank_kernel_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: (133,171) K=7, block_len=64 as 8 tiles of b=8, "
-                            "10M blocks/GPU @ SNR 2 dB, 3-layer FNN 16-128-64-32-256",
+                "workload": workload_label(n_blocks, dims),
                 "blocks_per_gpu": n_blocks, "rows_per_block": ROWS_PER_BLOCK,
                 "net": dims, "weights": weights_desc,
                 "parallelism": f"block-shard x{world}, counters all-reduce only",
@@ -296,6 +402,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision],
                 "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS[args.precision], "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel_ms_per_launch": launch_s * 1e3,
                 "algorithmic_flop_per_launch": flop_row * n_rows,
                 "algorithmic_bytes_per_launch": bytes_row * n_rows,

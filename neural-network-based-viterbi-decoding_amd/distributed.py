@@ -12,8 +12,9 @@ Decoded bits stay on the GPU that produced them.
 """
 from __future__ import annotations
 
+import datetime
 import os
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -27,6 +28,25 @@ def block_shard(n_blocks: int, rank: int, world_size: int) -> Tuple[int, int]:
     count = base + (1 if rank < rem else 0)
     first = rank * base + min(rank, rem)
     return first, count
+
+
+def group_timeout_s() -> float:
+    """Time limit of the rendezvous and of every collective (NNV_DIST_TIMEOUT_S, default 120 s): a stuck
+    RCCL bootstrap must end as an error with a message, not as a kill at some outer limit (PyTorch's own
+    default is 10 minutes)."""
+    return float(os.environ.get("NNV_DIST_TIMEOUT_S", "120"))
+
+
+def validate_group(ranks_seen: int, rank_devices: Sequence[int], world_size: int,
+                   require_distinct_devices: bool) -> None:
+    """The collective must have spanned exactly ``world_size`` ranks, and under RCCL every rank must sit on
+    its own GPU.  Raises RuntimeError (with both lists) otherwise: a benchmark must not print a value
+    for N GPUs that its one collective did not span."""
+    devs = [int(d) for d in rank_devices]
+    if int(ranks_seen) != int(world_size) or len(devs) != int(world_size):
+        raise RuntimeError(f"process group spans {ranks_seen} rank(s) (devices {devs}), expected {world_size}")
+    if require_distinct_devices and len(set(devs)) != int(world_size):
+        raise RuntimeError(f"{world_size} ranks share GPUs: rank_devices {devs} (one GPU per rank under RCCL)")
 
 
 def init_from_env(backend: Optional[str] = None, device_index: Optional[int] = None,
@@ -57,9 +77,11 @@ def init_from_env(backend: Optional[str] = None, device_index: Optional[int] = N
                                    f"{torch.cuda.device_count()} visible (RCCL needs one GPU per rank)")
             torch.cuda.set_device(idx)
             dist.init_process_group(backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", idx))
+                                    device_id=torch.device("cuda", idx),
+                                    timeout=datetime.timedelta(seconds=group_timeout_s()))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=group_timeout_s()))
     return rank, local_rank, world
 
 
@@ -72,6 +94,17 @@ def gather_ints(value: int, device=None, group=None) -> list:
     out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
     dist.all_gather(out, t, group=group)
     return [int(o.item()) for o in out]
+
+
+def gather_floats(value: float, device=None, group=None) -> list:
+    """[value of rank 0, value of rank 1, ...] on every rank (all_gather of one float64)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    on_host = device is None or dist.get_backend(group) == "gloo"
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if on_host else device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return [float(o.item()) for o in out]
 
 
 def all_reduce_counters(counters: torch.Tensor, group=None) -> torch.Tensor:

@@ -116,3 +116,116 @@ def test_bench_launches_its_own_ranks():
     assert "rank 0/2: needs an MI355X" in r.stderr and "rank 1/2: needs an MI355X" in r.stderr
     assert r.returncode != 0
     assert r.stdout.strip() == ""                   # no JSON line from a failed run
+
+
+# ------------------------------------------------------------------ guard rails
+def test_launcher_time_limit_terminates_a_stuck_child(tmp_path):
+    """A rendezvous that never completes must end with a diagnosis (which rank got how far), exit code 4
+    and no JSON line -- not hang until somebody else's limit.  The fake 'bench script' writes its stage
+    breadcrumb like a rank does and then sleeps."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "stuck_rank.py"
+    fake.write_text(
+        "import os, time\n"
+        "d = os.environ['NNV_BENCH_STAGE_DIR']\n"
+        "open(os.path.join(d, 'rank' + os.environ['RANK']), 'w').write('joining the process group')\n"
+        "open(os.path.join(%r, 'pid' + os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+        "time.sleep(600)\n" % str(tmp_path))
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.launch_ranks(2, 20.0, argv=[], script=%r))" % (root, str(fake)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 4
+    assert time.time() - t0 < 120
+    assert "did not finish within 20 s" in r.stderr
+    assert "0: 'joining the process group'" in r.stderr and "1: 'joining the process group'" in r.stderr
+    assert r.stdout.strip() == ""
+    time.sleep(1.0)
+    for rank in (0, 1):                                  # the stuck ranks are gone (their exact pids)
+        pid = int((tmp_path / f"pid{rank}").read_text())
+        alive = True
+        try:
+            os.kill(pid, 0)
+            with open(f"/proc/{pid}/stat") as f:
+                alive = f.read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive
+
+
+def test_validate_group_rules():
+    nd.validate_group(1, [0], 1, require_distinct_devices=False)
+    nd.validate_group(4, [0, 1, 2, 3], 4, require_distinct_devices=True)
+    nd.validate_group(2, [0, 0], 2, require_distinct_devices=False)         # the one-GPU gloo rehearsal
+    with pytest.raises(RuntimeError, match="share GPUs"):
+        nd.validate_group(2, [0, 0], 2, require_distinct_devices=True)
+    with pytest.raises(RuntimeError, match="spans 1 rank"):
+        nd.validate_group(1, [0], 2, require_distinct_devices=True)
+    with pytest.raises(RuntimeError):
+        nd.validate_group(2, [0], 2, require_distinct_devices=False)
+
+
+def _dup_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    nd.init_from_env(backend="gloo")
+    ones = torch.ones(1, dtype=torch.int64)
+    nd.all_reduce_counters(ones)
+    devices = nd.gather_ints(0)                       # forced duplicate: every rank claims GPU 0
+    per_rank = nd.gather_floats(1.5 + rank)
+    verdict = "ok"
+    try:
+        nd.validate_group(int(ones.item()), devices, world, require_distinct_devices=True)
+    except RuntimeError as e:
+        verdict = str(e)
+    with open(os.path.join(out_dir, f"v{rank}.txt"), "w") as f:
+        f.write(f"{verdict}|{per_rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_duplicate_devices_are_refused_on_every_rank_under_gloo(tmp_path):
+    mp.spawn(_dup_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        verdict, per_rank = (tmp_path / f"v{r}.txt").read_text().split("|")
+        assert "share GPUs" in verdict and "[0, 0]" in verdict
+        assert per_rank == "[1.5, 2.5]"               # bench.py's ms_per_step_per_rank gather
+
+
+def test_group_timeout_is_short_and_overridable(monkeypatch):
+    monkeypatch.delenv("NNV_DIST_TIMEOUT_S", raising=False)
+    assert nd.group_timeout_s() == 120.0
+    monkeypatch.setenv("NNV_DIST_TIMEOUT_S", "7")
+    assert nd.group_timeout_s() == 7.0
+
+
+def test_bench_labels_say_what_ran(tmp_path, monkeypatch):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    dims = [16, 128, 64, 32, 256]
+    full = bench.workload_label(10_000_000, dims)
+    assert full.startswith("BASELINE configs[2]") and "10M blocks/GPU" in full and "16-128-64-32-256" in full
+    red = bench.workload_label(4_000_000, dims)
+    assert red.startswith("REDUCED:") and "4M blocks/GPU" in red
+    assert "12,345 blocks/GPU" in bench.workload_label(12_345, dims)
+    # replayed traffic: only for the profiled launch size AND the kernel sources the counters were taken on
+    import json
+    with open(os.path.join(root, "profiles", "pmc_traffic.json")) as f:
+        tj = json.load(f)
+    t, src = bench.replayed_traffic(tj["rows_per_launch"] + 32)
+    assert t is None and "rows per launch" in src
+    t, src = bench.replayed_traffic(tj["rows_per_launch"])
+    if tj.get("k1_source_sha1") == bench.k1_source_hash():
+        assert t == tj["hbm_bytes_per_launch"] and "replayed" in src and "not measured in this run" in src
+    else:
+        assert t is None and "stale" in src
+    monkeypatch.setattr(bench, "k1_source_hash", lambda: "0" * 40)
+    t, src = bench.replayed_traffic(tj["rows_per_launch"])
+    assert t is None and "stale" in src

@@ -129,8 +129,14 @@ print("wrote", out_path)
 k = summary["kernels"]
 if "f32" in k and "hbm_bytes_per_launch" in k["f32"]:
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import hashlib
+    h = hashlib.sha1()   # bench.k1_source_hash(): the kernel sources these counters were taken on
+    for name in ("nnv_mlp_decode.hip", "nnv_mlp_launch.hip", "nnv_internal.h"):
+        with open(os.path.join(here, "neural-network-based-viterbi-decoding_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
     with open(os.path.join(here, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump({"rows_per_launch": ROWS, "hbm_bytes_per_launch": k["f32"]["hbm_bytes_per_launch"],
+                   "k1_source_sha1": h.hexdigest(),
                    "hbm_bytes_per_launch_f16x3": k.get("f16x3", {}).get("hbm_bytes_per_launch"),
                    "source": out_path}, f, indent=1)
     print("updated profiles/pmc_traffic.json")
