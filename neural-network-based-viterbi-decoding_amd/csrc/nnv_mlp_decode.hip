@@ -32,10 +32,15 @@
 //  * Received soft bits are read once, as per-lane contiguous half rows
 //    (a wave reads one contiguous 32*n_in*4-byte span), prefetched one tile
 //    ahead; decoded classes are written as one 128-byte store per tile.
+#include <type_traits>
+
 #include "nnv_internal.h"
 
 #ifndef NNV_CLASS_GROUP
 #define NNV_CLASS_GROUP 2
+#endif
+#ifndef NNV_RING_LATE_X
+#define NNV_RING_LATE_X 1
 #endif
 
 namespace nnv {
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       if constexpr (NHID == 1) {
 #pragma unroll
         for (int mt = 0; mt < MTA; ++mt) ha[mt].set(layer1_tile(mt));
-        if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
+        if ((!STREAM || !NNV_RING_LATE_X || n_slots == 0) && next_tile < p.n_tiles) fetch_x(next_tile, xn);
         NNV_STAMP(1);
       } else {
         f32x16 acc2[MTB];
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
             acc2[mt] = dense_tile<PREC, 1>(a, lds + W1F + (mt * MTA + kt) * 4 * kFragGroupFloats + lo, acc2[mt]);
         }
         NNV_STAMP(1);  // layer 1 + layer 2 MFMAs
-        if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
+        if ((!STREAM || !NNV_RING_LATE_X || n_slots == 0) && next_tile < p.n_tiles) fetch_x(next_tile, xn);
 #pragma unroll
         for (int mt = 0; mt < MTB; ++mt) {
           act16<PREC>(acc2[mt]);
@@ -587,35 +592,68 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       }
     }
     // Stream variant: the remaining class tiles, swept by all waves of the workgroup TOGETHER through
-    // the two-slot LDS ring.  Phase s (global count over rounds): barrier -- the DMA of slot s, issued
-    // one whole phase earlier, has landed in buffer s & 1 for every wave (__syncthreads waits vmcnt(0)
-    // first) and nobody still reads buffer (s + 1) & 1 --, then the DMA of slot s + 1 into that buffer,
-    // then RT class tiles of MFMAs from buffer s & 1.  Each streamed fragment leaves L2 once per
-    // workgroup and round (round 2: once per WAVE, 152 KB per row tile of configs[1], with a prefetch
-    // distance of 4 MFMAs) and every class tile is consumed from LDS, the path that sustains 64
-    // cycles per MFMA.
+    // the two-slot LDS ring.  Phase s (global count over rounds): wait for this wave's own DMA (vmcnt),
+    // barrier -- slot s has landed in buffer s & 1 for every wave and nobody still reads buffer
+    // (s + 1) & 1 --, then the DMA of slot s + 1 into that buffer (a whole phase ahead of its use), then
+    // RT class tiles of MFMAs from buffer s & 1.  Each streamed fragment leaves L2 once per workgroup and
+    // round (round 2: once per WAVE, 152 KB per row tile of configs[1], prefetched 4 MFMAs ahead) and
+    // every class tile is consumed from LDS, the path that sustains 64 cycles per MFMA.
+    //  Two things keep the phase boundary short (s_memtime stamps of the first version, plain
+    // __syncthreads() between "MFMAs + argmax" phases: 1.3 k of ~10 k cycles per phase with the matrix
+    // pipe idle).  (1) The argmax of a slot is DEFERRED to the start of the next phase: a wave reaches the
+    // barrier right after ISSUING its last MFMA -- no wait for the chain to finish, no argmax, no winner
+    // parking behind it --, and behind the barrier the previous slot's argmax runs under the latency of
+    // the first fragment read.  (2) The barrier is the RAW s_barrier behind a vmcnt-only wait:
+    // __syncthreads() also drains lgkmcnt, i.e. every wave's parked-winner writes and bias reads, which
+    // need no cross-wave visibility (the winner slots are private to a lane, the biases never change).
     if constexpr (STREAM) {
-      for (int i = 0; i < n_slots; ++i) {
-        NNV_STAMP(4);  // resident class tiles / previous slot's MFMAs + argmax
-        __syncthreads();
-        NNV_STAMP(6);  // barrier (incl. the wait for this wave's DMA)
+      f32x16 accp;       // the LAST class tile of the slot whose MFMAs were issued before the barrier:
+      int pending = -1;  // its argmax is still pending (tile id, wave-uniform; -1: none)
+      auto retire = [&]() {
+        if (pending >= 0 && pending < p.mt_out) finish_class_tile(accp, pending);
+      };
+      // one ring phase; LAST = the round's final slot, peeled off the loop so that the NEXT round's soft
+      // bits are requested there (a phase, ~4 us, ahead of their use) instead of during the hidden layers:
+      // 4 G1 registers that would otherwise sit idle through the whole class sweep
+      auto ring_phase = [&](int i, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        NNV_STAMP(4);  // resident class tiles / this phase's argmax + MFMA issue
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of slot `phase` has landed
+        NNV_STAMP(6);
+#ifndef NNV_EXPERIMENT_NO_BARRIER   // timing experiment only (races): what the lock step itself costs
+        __builtin_amdgcn_s_barrier();
+#endif
+        asm volatile("" ::: "memory");                    // no LDS access may move across the barrier
+        NNV_STAMP(7);  // all waves arrived
         ++phase;
-        if (phase < total_phases) ring_fill(i + 1 == n_slots ? 0 : i + 1, static_cast<int>(phase & 1));
+#ifndef NNV_EXPERIMENT_NO_DMA       // timing experiment only (stale weights): what the ring fill costs
+        if (phase < total_phases) ring_fill(LAST ? 0 : i + 1, static_cast<int>(phase & 1));
+#endif
+        if constexpr (LAST && NNV_RING_LATE_X) {
+          if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
+        }
         if (valid) {
+          retire();
           const float *slot = ring + static_cast<int>((phase - 1) & 1) * SLOT_FLOATS + lo;
           const int mtb = p.out_lds_tiles + i * RT;
-          f32x16 accs[RT];
+          // all but the slot's last tile are finished in the phase; only the last one (16 registers) is
+          // carried across the barrier
 #pragma unroll
           for (int t = 0; t < RT; ++t) {
             const int mt = mtb + t < p.mt_out ? mtb + t : p.mt_out - 1;
-            accs[t] = init_acc(lds + BOOFF + 32 * mt, half);
-            accs[t] = dense_tile<PREC, KT_OUT>(hlast, slot + t * GPT * kFragGroupFloats, accs[t]);
+            f32x16 acc = dense_tile<PREC, KT_OUT>(hlast, slot + t * GPT * kFragGroupFloats, init_acc(lds + BOOFF + 32 * mt, half));
+            if (t + 1 < RT) {
+              if (mtb + t < p.mt_out) finish_class_tile(acc, mtb + t);
+            } else {
+              accp = acc;
+            }
           }
-#pragma unroll
-          for (int t = 0; t < RT; ++t)
-            if (mtb + t < p.mt_out) finish_class_tile(accs[t], mtb + t);
+          pending = mtb + RT - 1;
         }
-      }
+      };
+      for (int i = 0; i + 1 < n_slots; ++i) ring_phase(i, std::false_type{});
+      if (n_slots > 0) ring_phase(n_slots - 1, std::true_type{});
+      if (valid) retire();
     }
     if constexpr (KEEP_LDS) {
 #pragma unroll

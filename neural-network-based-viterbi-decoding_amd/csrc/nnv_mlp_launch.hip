@@ -53,7 +53,9 @@ int pick_threads_impl(const PackedShape &s) {
     if (!k) continue;
     hipFuncAttributes attr;
     if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) continue;
-    if (attr.localSizeBytes <= 32) return nt;  // up to 8 spilled dwords cost less than a wave per SIMD
+    // up to 8 spilled dwords cost less than a wave per SIMD; the stream variant's spills (<= 16 dwords) sit in
+    // per-row-tile code, outside its ring loop (configs[1], same box: 0.846 at 1024 threads, 0.79 at 512)
+    if (attr.localSizeBytes <= (s.streams ? 64u : 32u)) return nt;
   }
   return 512;
 }

@@ -29,16 +29,23 @@ def matched_filter_network(b, n_layers):
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--weights", choices=("matched", "random"), default="matched",
+                help="matched: the matched-filter network (meaningful BER, but mostly zero weights); random: seeded "
+                     "truncated-normal init of the reference (dense operands: MFMA power draw is data dependent)")
 args = ap.parse_args()
 for name, block_len, n_blocks, n_layers, snr_db in (("configs[0]", 20, 1_000, 3, 2.0), ("configs[1]", 100, 1_000_000, 2, 4.0)):
     b = 10
     rpb = block_len // b
     n = n_blocks * rpb
     Ws, bs, dims = matched_filter_network(b, n_layers)
+    if args.weights == "random":
+        rng = np.random.RandomState(5)
+        Ws = [fv.truncated_normal((dims[i], dims[i + 1]), np.sqrt(2.0 / dims[i]), rng) for i in range(len(dims) - 1)]
+        bs = [(rng.randn(d) * 0.1).astype(np.float32) for d in dims[1:]]
     sigma = float(fv.DecoderConfig(block_length=b, snr_db=snr_db).sigma)
     x, lab = generate_awgn_blocks("57", b, n, sigma, seed=11, rows_per_block=rpb)
     out = {"metric": f"decoded blocks/sec, (7,5) block_len={block_len} @ SNR {snr_db} dB, {n_layers}-layer FNN",
-           "config": name, "blocks": n_blocks, "rows_per_block": rpb, "net": dims, "unit": "blocks/s"}
+           "config": name, "weights": args.weights, "blocks": n_blocks, "rows_per_block": rpb, "net": dims, "unit": "blocks/s"}
     flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
     for prec in ("f32", "f16x3"):
         net = PackedMLP(Ws, bs, precision=prec)

@@ -23,7 +23,7 @@ buf = (ctypes.c_ulonglong * 16)()
 assert lib.nnv_debug_read_stamps(buf) == 0
 v = [int(t) for t in buf]
 tiles = v[8]
-names = ["x wait/top", "layer1", "layer2 act", "layer3", "class: resident + slot compute", "epilogue", "barrier wait", "-"]
+names = ["x wait/top", "layer1", "layer2 act", "layer3", "class: resident + slot compute", "epilogue", "wait vmcnt(0)", "s_barrier"]
 info = net.launch_info(n)
 print(f"threads {info['threads']} lds_tiles {info['class_tiles_in_lds']} {ms:.3f} ms for {n} rows; row tiles by wave0: {tiles}")
 tot = sum(v[:8])
