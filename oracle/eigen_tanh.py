@@ -20,7 +20,18 @@ float32, as here.  The GEMM feeding it is Eigen's blocked gebp kernel; for depth
 ``matmul_seq_k`` restates (product rounded, then added: no FMA); ``forward_tf_like(seq_k=True)`` is the
 closest statement of TensorFlow-1.x's CPU forward pass available without TensorFlow, numpy's BLAS matmul
 (``seq_k=False``) the quick stand-in.  Neither is a pin: thread partitioning, packet width and
-compiler flags of the actual build are not known."""
+compiler flags of the actual build are not known.
+
+Version caveat (the clamp).  This file fixes the clamp at +-9, the constant of the Eigen snapshots of the
+TensorFlow 1.0 - 1.13 era.  Later Eigen revisions (vendored by TF 1.14/1.15 and 2.x) clamp at
++-7.90531110763549805 instead ("the smallest |x| for which the rational function already rounds to +-1 in
+float32") and keep the same coefficients.  Which of the two the reference's user ran depends on the
+TensorFlow 1.x wheel they had (requirements.txt:2 pins a range that does not even contain a working one), so
+the constant is a parameter of the arbiter, not a known fact about the reference: ``tanh(a, clamp=...)``
+takes either, the self-check runs for both, and the class-flip tables of DESIGN.md section 2 quote +-9.  The
+two differ only for |x| in (7.905, 9], where the late one returns exactly +-1 and the early one values within
+4.5e-7 of it (1 - 2^-24 ... 1 + 2^-22) -- inside the flat
+top that the decode kernel's kFlatBand path (>= 7.9) already treats as ties."""
 from __future__ import annotations
 
 import numpy as np
@@ -33,9 +44,13 @@ _BETA = [_F(v) for v in (4.89352518554385e-03, 2.26843463243900e-03, 1.185347056
                          1.19825839466702e-06)]            # denominator, x^0, x^2, x^4, x^6
 
 
-def tanh(a):
+CLAMP_TF_EARLY = 9.0                      # Eigen snapshots vendored by TF 1.0 - 1.13
+CLAMP_TF_LATE = 7.90531110763549805       # Eigen from 2019 on (TF 1.14+)
+
+
+def tanh(a, clamp=CLAMP_TF_EARLY):
     """float32 in, float32 out; every intermediate rounded to float32 (mul, then add)."""
-    x = np.clip(np.asarray(a, dtype=_F), _F(-9.0), _F(9.0))
+    x = np.clip(np.asarray(a, dtype=_F), _F(-clamp), _F(clamp))
     x2 = x * x
     p = x2 * _ALPHA[6] + _ALPHA[5]
     for k in (4, 3, 2, 1, 0):

@@ -738,8 +738,17 @@ def test_torch_custom_op(cuda_device):
     _assert_parity(c, None, x, Ws, bs, b)
     assert np.array_equal(bits.cpu().numpy(), O.class_to_bits(c, b))
     assert np.array_equal(counters.cpu().numpy(), O.error_counters(c, labels, b))
-    with pytest.raises(Exception):
-        torch.ops.nnviterbi.mlp_decode(torch.from_numpy(x), tw, tb, b, None)   # CPU tensor: no kernel
+    with pytest.raises(Exception):     # mixed devices (CPU rows, HIP weights) are refused, whichever key is picked
+        torch.ops.nnviterbi.mlp_decode(torch.from_numpy(x), tw, tb, b, None)
+    # all-CPU arguments take the CPU dispatch key (plain torch ops; BASELINE configs[0] "plumbing, no GPU")
+    ccls, cbits, ccnt = torch.ops.nnviterbi.mlp_decode(
+        torch.from_numpy(x), [torch.from_numpy(w) for w in Ws], [torch.from_numpy(v) for v in bs], b,
+        torch.from_numpy(labels))
+    assert not ccls.is_cuda and ccls.dtype == torch.int64
+    _assert_parity(ccls.numpy(), None, x, Ws, bs, b)
+    assert (ccls.numpy() != c).sum() <= 1                      # two fp32 evaluation orders: near-ties only
+    assert np.array_equal(cbits.numpy(), O.class_to_bits(ccls.numpy(), b))
+    assert np.array_equal(ccnt.numpy(), O.error_counters(ccls.numpy(), labels, b))
     out = torch.ops.nnviterbi.mlp_forward(torch.from_numpy(x).cuda(), tw, tb)
     assert out.shape == (n, 256) and np.abs(out.cpu().numpy() - O.forward(x, Ws, bs, np.float64)).max() < TOL
 

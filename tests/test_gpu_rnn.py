@@ -153,3 +153,56 @@ def test_committed_fixture(cuda_device, name, precision):
     got = net.forward(enc, dec)["logits"]
     assert np.abs(got.cpu().numpy() - g[f"{name}_logits64"]).max() < TOL
     net.close()
+
+
+@pytest.mark.timeout(900)
+def test_baseline_config4_at_full_size(cuda_device):
+    """BASELINE configs[4] AT ITS STATED SIZE: 10 M blocks x block_len 256 -> 512 encoder + 512 decoder
+    steps over a [512, 10 M] time-major batch (~65 GB resident), through size-independent properties,
+    as test_full_size_round_trip... does for configs[2].
+    LSTM, not GRU: BASELINE.json says "GRU forward", the reference builds tf.contrib.rnn.LSTMCell
+    (src/rnn_viterbi.py:289-321) and that is what is decoded here; parity UNPINNED (see the module docstring).
+      * every logit finite;
+      * hard bits and error counters recomputed from the logits with torch (exact integer functions);
+      * a second launch reproduces the logits bit for bit;
+      * block-permutation equivariance: 4,096 blocks cut from the middle, shuffled and decoded on their own,
+        give the same logits bit for bit (a block's logits depend on that block alone);
+      * an oracle sample: 2,048 blocks from the middle against the float64 restatement within TOL."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * 2**30:
+        pytest.skip("needs ~150 GB of free HBM for the full-size feeds and their generation temporaries")
+    L, B, H = 256, 10_000_000, 20
+    p = _params(H, 21)
+    net = Seq2SeqLSTM(p)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    info = torch.rand((L, B), device="cuda", generator=g) > 0.5
+    # the reference's feeds: int-truncated noisy BPSK symbols (SURVEY F12), [EOS | +-1 info | zeros]
+    enc = torch.randn((2 * L, B), device="cuda", generator=g).sign_()
+    enc.add_(torch.randn((2 * L, B), device="cuda", generator=g).mul_(0.5616748812614791)).trunc_()
+    dec = torch.zeros((2 * L, B), device="cuda")
+    dec[0] = 1.0
+    dec[1:L + 1] = info.float().mul_(2).sub_(1)
+    info_u8 = info.to(torch.uint8).contiguous()
+    del info
+    counters = torch.zeros(4, dtype=torch.int64, device="cuda")
+    r = net.forward(enc, dec, info_bits=info_u8, n_bits=L, want_bits=True, counters=counters)
+    logits, bits = r["logits"], r["bits"]
+    assert logits.shape == (2 * L, B) and bool(torch.isfinite(logits).all())
+    want_bits = (logits[:L] > 0).to(torch.uint8)
+    assert torch.equal(bits, want_bits)
+    diff = want_bits != info_u8
+    want = torch.stack([diff.sum(), diff.any(dim=0).sum(), torch.tensor(L * B, device="cuda"),
+                        torch.tensor(B, device="cuda")]).to(torch.int64)
+    assert torch.equal(counters, want)
+    del want_bits, diff
+    again = net.forward(enc, dec)["logits"]
+    assert torch.equal(again, logits)
+    del again
+    mid = B // 2 + 13                                     # not a multiple of the 32-block wave tile
+    perm = torch.randperm(4096, device="cuda", generator=g)
+    sub = net.forward(enc[:, mid:mid + 4096][:, perm].contiguous(), dec[:, mid:mid + 4096][:, perm].contiguous())["logits"]
+    assert torch.equal(sub, logits[:, mid:mid + 4096][:, perm])
+    m = 2048
+    want64, _ = R.seq2seq_forward(enc[:, mid:mid + m].cpu().numpy(), dec[:, mid:mid + m].cpu().numpy(), p, np.float64)
+    assert np.abs(logits[:, mid:mid + m].cpu().numpy() - want64).max() < TOL
+    net.close()

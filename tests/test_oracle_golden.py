@@ -202,3 +202,16 @@ def test_eigen_fast_tanh_restatement_self_check():
     assert E.tanh(np.array([9.0, 30.0, -30.0], np.float32)).tolist() == [1.0, 1.0, -1.0]
     assert e.max() > 1.0 and (np.diff(e) < 0).sum() > 1000          # overshoot; ulp-level non-monotonicity
     assert E.tanh(np.array([8.5], np.float32))[0] == 1.0 and E.tanh(np.array([8.8], np.float32))[0] < 1.0
+
+
+def test_eigen_fast_tanh_clamp_versions_agree_outside_the_flat_top():
+    """The clamp constant is Eigen-version dependent (+-9 in the snapshots TF 1.0-1.13 vendor, +-7.905 later):
+    both are inside 4.5e-7 of float64 tanh, identical for |x| <= 7.905, and differ by at most 4.5e-7 above --
+    the flat top the decode kernel already treats as ties (oracle/eigen_tanh.py "Version caveat")."""
+    from oracle import eigen_tanh as E
+    xs = np.linspace(-10, 10, 400001).astype(np.float32)
+    early, late = E.tanh(xs, E.CLAMP_TF_EARLY), E.tanh(xs, E.CLAMP_TF_LATE)
+    assert np.abs(late - np.tanh(xs.astype(np.float64))).max() < 4.5e-7
+    inside = np.abs(xs) <= np.float32(E.CLAMP_TF_LATE)
+    assert np.array_equal(early[inside], late[inside])
+    assert np.abs(early - late).max() < 4.5e-7 and np.all(np.abs(late[~inside]) == 1.0)
