@@ -63,7 +63,7 @@ TILE_BITS = 8                      # b: largest divisor of 64 that is <= 10
 ROWS_PER_BLOCK = BLOCK_LEN // TILE_BITS
 SNR_DB = 2.0
 # /opt/skills/guides/MI355X_MICROARCH.md:42-43: dense MFMA peaks per operand dtype
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}
 SEED = 20240607
 
 
@@ -258,7 +258,7 @@ def main():
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("NNV_LAUNCH_TIMEOUT_S", "300")),
                     help="bare `--gpus N` only: seconds the self-launched ranks get before they are terminated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=("f32", "f16x3"), default="f32",
+    ap.add_argument("--precision", choices=("f32", "f16x3"), default="f32",   # "f16" is reported beside, never measured as `value`
                     help="f32: exact fp32 MFMA chain (headline, parity reference); "
                          "f16x3: hi/lo f16 split operands, fp32 accumulate")
     args = ap.parse_args()
@@ -376,6 +376,29 @@ def main():
     ber2, _ = nd.rates(counters2.cpu().numpy())
     net2.close()
 
+    # ---- the single-product f16 mode (opt-in, outside the parity contract): speed AND what it costs ----
+    net3 = PackedMLP(Ws, bs, device=dev, precision="f16")
+    counters3 = torch.zeros(4, dtype=torch.int64, device=dev)
+    for _ in range(args.warmup):
+        net3.decode_timed(x, labels, cls2, counters3, 1, tile_bits=TILE_BITS)
+    counters3.zero_()
+    nd.barrier(dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    net3.decode_timed(x, labels, cls2, counters3, args.steps, tile_bits=TILE_BITS)
+    torch.cuda.synchronize(dev)
+    nd.barrier(dev)
+    elapsed3 = nd.max_over_ranks(time.perf_counter() - t0, device=dev)
+    f16_flips = torch.tensor([int((cls2 != cls).sum().item())], dtype=torch.int64, device=dev)
+    nd.all_reduce_counters(f16_flips)
+    nd.all_reduce_counters(counters3)
+    ber3, _ = nd.rates(counters3.cpu().numpy())
+    f16_out_err = None
+    if rank == 0 and args.precision == "f32":
+        m = min(n_rows, 200_000)            # max |out - out_f32 mode| on a sample, through the debug forward entry
+        f16_out_err = float((net3.forward(x[:m]) - net.forward(x[:m])).abs().max().item())
+    net3.close()
+
     if rank == 0:
         flop_row, bytes_row = algorithmic_work(dims)
         launch_s = kernel_ms / 1e3 / args.steps
@@ -414,6 +437,14 @@ def main():
                 "ms_per_step": elapsed2 * 1e3 / args.steps, "ber": ber2,
                 "classes_differing_from_headline_mode_rank0": class_diff, "rows_rank0": n_rows,
             },
+        }
+        out["fast_mode_f16"] = {
+            "dtype": "f16", "value": world * n_blocks * args.steps / elapsed3, "unit": "blocks/s",
+            "ms_per_step": elapsed3 * 1e3 / args.steps, "ber": ber3, "ber_delta_vs_headline_mode": ber3 - ber,
+            "class_flip_rate_vs_headline_mode": int(f16_flips.item()) / float(world * n_rows),
+            "max_abs_output_difference_from_f32_mode_sample": f16_out_err,
+            "note": "operands rounded once to f16, one MFMA per product block: OUTSIDE the 1e-5 parity contract "
+                    "(tests/test_gpu_f16_mode.py states its own tolerance); BASELINE's bar for it is |dBER| <= 1e-4",
         }
         if world == 1 and not args.no_cpu_baseline:
             base, parity = cpu_baseline(x, labels, Ws, bs, cls)

@@ -50,9 +50,13 @@ typedef enum nnv_status {
 /* Arithmetic of the dense layers (nnv_mlp_prepack_ex). */
 typedef enum nnv_precision {
   NNV_PRECISION_F32 = 0,   /* fp32 operands, fp32 MFMA: an exact fp32 fmaf chain  */
-  NNV_PRECISION_F16X3 = 1  /* operands split hi+lo into two f16 (22 bits), three
+  NNV_PRECISION_F16X3 = 1, /* operands split hi+lo into two f16 (22 bits), three
                               f16 MFMAs per product block, fp32 accumulate:
                               ~2^-21 relative error per product, ~3x faster    */
+  NNV_PRECISION_F16 = 2    /* nnv_mlp_* only: operands rounded ONCE to f16 (11 bits), one f16 MFMA
+                              per product block, fp32 accumulate.  OUTSIDE the 1e-5 parity contract
+                              (outputs within ~2e-3 of float64; class flips and BER delta are reported
+                              by bench.py): the opt-in "fast mode with measured BER delta"            */
 } nnv_precision;
 
 /* Convolutional codes of the reference's generators. */

@@ -29,7 +29,7 @@ nnv_status shape_from_desc(const nnv_mlp_desc *net, int32_t precision, PackedSha
     if (net->dims[l] < 1) return NNV_ERR_INVALID_ARGUMENT;
   for (int l = 0; l < net->depth; ++l)
     if (!net->W_host[l] || !net->b_host[l]) return NNV_ERR_INVALID_ARGUMENT;
-  if (precision != nnv::kPrecF32 && precision != nnv::kPrecF16x3) return NNV_ERR_INVALID_ARGUMENT;
+  if (precision != nnv::kPrecF32 && precision != nnv::kPrecF16x3 && precision != nnv::kPrecF16) return NNV_ERR_INVALID_ARGUMENT;
   memset(s, 0, sizeof(*s));
   s->precision = precision;
   s->depth = net->depth;
@@ -41,11 +41,13 @@ nnv_status shape_from_desc(const nnv_mlp_desc *net, int32_t precision, PackedSha
   s->n_classes = net->dims[net->depth];
   s->mt_out = ceil_div(s->n_classes, 32);
   s->kt_out = s->mt[s->nhid - 1];
-  // fp32: g1 groups per M-tile; f16x3: (g1/2) k-steps x {hi, lo} = g1 groups as well
-  s->hid_floats = static_cast<int64_t>(s->mt[0]) * s->g1 * nnv::kFragGroupFloats;
+  // fp32: g1 groups per M-tile; f16x3: (g1/2) k-steps x {hi, lo} = g1 groups as well; f16: hi only = g1/2
+  const int l1_groups = precision == nnv::kPrecF16 ? s->g1 / 2 : s->g1;
+  const int64_t kt_floats = static_cast<int64_t>(nnv::class_tile_kb(precision, 1)) * 256;  // per (M-tile, k-tile)
+  s->hid_floats = static_cast<int64_t>(s->mt[0]) * l1_groups * nnv::kFragGroupFloats;
   for (int i = 1; i < s->nhid; ++i)
-    s->hid_floats += static_cast<int64_t>(s->mt[i]) * s->mt[i - 1] * 4 * nnv::kFragGroupFloats;
-  s->out_floats = static_cast<int64_t>(s->mt_out) * s->kt_out * 4 * nnv::kFragGroupFloats;
+    s->hid_floats += static_cast<int64_t>(s->mt[i]) * s->mt[i - 1] * kt_floats;
+  s->out_floats = static_cast<int64_t>(s->mt_out) * s->kt_out * kt_floats;
   int mts = s->mt_out;
   for (int i = 0; i < s->nhid; ++i) mts += s->mt[i];
   s->bias_floats = 32LL * mts;
@@ -62,7 +64,8 @@ nnv_status shape_from_desc(const nnv_mlp_desc *net, int32_t precision, PackedSha
 // i.e. W_eff = s_l * f_l * W and b_eff = s_l * (b + [l >= 2] sum_k W_k) with s_l = c for hidden
 // layers, 1 for the class layer, f_l = 1 for layer 1, -2 after.  Computed in double and split
 // into hi/lo halves from the double (22 significant bits), the same algebraic function.
-bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vector<float> *out) {
+// planes = 2: hi and lo groups (f16x3);  planes = 1: the hi groups only (single-product f16 mode)
+bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vector<float> *out, int planes = 2) {
   out->assign(static_cast<size_t>(s.hid_floats + s.out_floats + s.bias_floats), 0.f);
   uint16_t *w = reinterpret_cast<uint16_t *>(out->data());
   bool in_range = true;
@@ -71,8 +74,9 @@ bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vect
     if (!(v > -65504.0 && v < 65504.0)) in_range = false;
     const uint16_t h = f32_to_f16(static_cast<float>(v));
     *hi = h;
-    *lo = f32_to_f16(static_cast<float>(v - static_cast<double>(f16_to_f32(h))));
+    if (planes == 2) *lo = f32_to_f16(static_cast<float>(v - static_cast<double>(f16_to_f32(h))));
   };
+  const int group_u16 = 512 * planes;  // uint16 per k-step: hi group (+ lo group)
   auto layer_scale = [&](int l) { return l == net->depth - 1 ? 1.0 : kTwoLog2e; };
   // a group = 64 lanes x 8 halves = 512 uint16; hi group then lo group per k-step
   {
@@ -90,7 +94,7 @@ bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vect
             const double v = (t < s.bp && k < s.n_in && i < M) ? sc * W[static_cast<size_t>(k) * M + i] : 0.0;
             emit(v, w + lane * 8 + e, w + 512 + lane * 8 + e);
           }
-        w += 1024;
+        w += group_u16;
       }
   }
   for (int l = 1; l < net->depth; ++l) {
@@ -110,7 +114,7 @@ bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vect
               const double v = (k < K && i < M) ? sc * W[static_cast<size_t>(k) * M + i] : 0.0;
               emit(v, w + lane * 8 + e, w + 512 + lane * 8 + e);
             }
-          w += 1024;
+          w += group_u16;
         }
   }
   float *bf = reinterpret_cast<float *>(w);
@@ -277,8 +281,9 @@ int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision, nnv_mlp_h
   if ((s0.hid_floats + s0.bias_floats) * 4 > kLdsLimitBytes) return NNV_ERR_UNSUPPORTED_SHAPE;
 
   std::vector<float> packed;
-  if (s0.precision == nnv::kPrecF16x3) {
-    if (!pack_network_f16x3(net, s0, &packed)) return NNV_ERR_UNSUPPORTED_SHAPE;  // weight outside f16 range
+  if (s0.precision != nnv::kPrecF32) {
+    if (!pack_network_f16x3(net, s0, &packed, s0.precision == nnv::kPrecF16x3 ? 2 : 1))
+      return NNV_ERR_UNSUPPORTED_SHAPE;  // weight outside f16 range
   } else {
     pack_network(net, s0, &packed);
   }

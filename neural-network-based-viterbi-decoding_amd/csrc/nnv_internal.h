@@ -82,6 +82,7 @@ inline float f16_to_f32(uint16_t h) {
 //                                         + 8((8s+e)>>2) + 4(lane>>5)  (accumulator register 8s+e)
 constexpr int kPrecF32 = 0;
 constexpr int kPrecF16x3 = 1;
+constexpr int kPrecF16 = 2;   // single-product f16: the hi planes of the f16x3 layout only
 // fp32 mode: hidden activations travel as r = 1/(1+2^zeta) with tanh's affine map 1 - 2r folded
 // into the next layer's packed weights (as the f16x3 mode always does).  Kernel (act16) and packer
 // (pack_network) must agree; 0 only in A/B builds.
@@ -93,12 +94,12 @@ constexpr int kFragGroupFloats = 256;
 constexpr int kRowsPerTile = 32;  // batch rows per wave tile (MFMA N dim)
 
 struct PackedShape {
-  int32_t precision;    // kPrecF32 | kPrecF16x3
+  int32_t precision;    // kPrecF32 | kPrecF16x3 | kPrecF16
   int32_t depth;        // dense layers incl. output
   int32_t nhid;         // depth - 1
   int32_t n_in;         // dims[0]
   int32_t bp;           // ceil(n_in / 2): layer-1 K steps actually used
-  int32_t g1;           // fp32: ceil(bp / 4) layer-1 groups per M-tile; f16x3: 2 * ceil(bp / 8)
+  int32_t g1;           // fp32: ceil(bp / 4) layer-1 groups per M-tile; 16-bit modes: 2 * ceil(bp / 8) (kernel template G1)
   int32_t mt[3];        // hidden layers' M-tiles (width padded to 32)
   int32_t n_classes;    // dims[depth]
   int32_t mt_out;       // ceil(n_classes / 32)
@@ -158,9 +159,10 @@ constexpr bool kKeepLds = kDeferArgmax && NNV_KEEP_LDS != 0;
 #ifndef NNV_RING_KB_F16
 #define NNV_RING_KB_F16 8
 #endif
+constexpr int class_tile_kb(int prec, int kt_out) { return (prec == kPrecF16 ? 2 : 4) * kt_out; }
 constexpr int ring_tiles_per_slot(int prec, int kt_out) {
   const int kb = prec == kPrecF32 ? NNV_RING_KB_F32 : NNV_RING_KB_F16;
-  return kb / (4 * kt_out) >= 1 ? kb / (4 * kt_out) : 1;
+  return kb / class_tile_kb(prec, kt_out) >= 1 ? kb / class_tile_kb(prec, kt_out) : 1;
 }
 
 constexpr int kMaxBins = 16;

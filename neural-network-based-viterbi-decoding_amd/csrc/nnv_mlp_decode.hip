@@ -63,6 +63,11 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 //   this mode is bound by instruction issue (tanh / split / argmax), not by the
 //   matrix pipe; its activations travel as r = 1/(1+e^{2z}) with tanh's affine map
 //   folded into the packed weights (act16, pack_network_f16x3).
+// PREC = kPrecF16   : the single-product 16-bit mode (SURVEY section 7 step 4's "fast mode with measured
+//   BER delta"): every operand rounded ONCE to f16 (11 significant bits), one v_mfma_f32_32x32x16_f16 per
+//   product block, fp32 accumulate; no lo plane, no residual v_fma_mix.  Same geometry and activation
+//   hand-over as f16x3, half its LDS footprint.  OUTSIDE the 1e-5 parity contract (outputs within ~2e-3
+//   of float64): opt-in, reported with its measured class-flip rate and BER delta, never as `value`.
 
 // tanh(z) = 1 - 2 / (1 + e^{2z});  e^{2z} = 2^{z * 2 log2(e)}.
 // v_exp_f32 and v_rcp_f32 are 1-ulp hardware approximations; the absolute
@@ -131,6 +136,25 @@ struct ActTile<kPrecF16x3> {
   }
 };
 
+template <>
+struct ActTile<kPrecF16> {
+  u32x4 hi[2];
+  __device__ __forceinline__ void set(const f32x16 &a) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x2 x = {a[8 * s + 2 * q], a[8 * s + 2 * q + 1]};
+        hi[s][q] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));  // v_cvt_pk_f16_f32 (RNE)
+      }
+  }
+};
+
+// floats of packed weights per (M-tile, k-tile of 32 inputs): fp32 4 groups of 4 k-steps; f16x3 2 k-steps x
+// {hi, lo}; f16 2 k-steps x {hi}
+template <int PREC>
+constexpr int kKtFloats = (PREC == kPrecF16 ? 2 : 4) * kFragGroupFloats;
+
 // acc += W_tile^T * (KT activation tiles).  wbase points at this M-tile's
 // fragment groups (already offset by the lane): 1024 floats per k-tile in both
 // precisions (fp32: 4 groups of [lane][4 steps]; f16x3: 2 k-steps x {hi, lo} of
@@ -146,13 +170,19 @@ __device__ __forceinline__ f32x16 dense_tile(const ActTile<PREC> (&in)[KT], Ptr 
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = mfma32(a[e], in[kt].v[4 * q + e], acc);
       }
-    } else {
+    } else if constexpr (PREC == kPrecF16x3) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const u32x4 ahi = *reinterpret_cast<const u32x4 *>(wbase + ((kt * 2 + s) * 2 + 0) * kFragGroupFloats);
         const u32x4 alo = *reinterpret_cast<const u32x4 *>(wbase + ((kt * 2 + s) * 2 + 1) * kFragGroupFloats);
         acc = mfma16(alo, in[kt].hi[s], acc);  // small terms first
         acc = mfma16(ahi, in[kt].lo[s], acc);
+        acc = mfma16(ahi, in[kt].hi[s], acc);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const u32x4 ahi = *reinterpret_cast<const u32x4 *>(wbase + (kt * 2 + s) * kFragGroupFloats);
         acc = mfma16(ahi, in[kt].hi[s], acc);
       }
     }
@@ -283,10 +313,12 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   constexpr int KS1 = (G1 + 1) / 2;
   constexpr int XN = PREC == kPrecF32 ? 4 * G1 : 8 * KS1;     // x values held per lane
   constexpr int XG = XN / 4;
-  constexpr int L1_PER_MT = PREC == kPrecF32 ? G1 * kFragGroupFloats : KS1 * 2 * kFragGroupFloats;
+  constexpr int PLANES = PREC == kPrecF16x3 ? 2 : 1;  // hi (+ lo) operand planes of the 16-bit modes
+  constexpr int L1_PER_MT = PREC == kPrecF32 ? G1 * kFragGroupFloats : KS1 * PLANES * kFragGroupFloats;
+  constexpr int KTF = kKtFloats<PREC>;
   constexpr int W1F = MTA * L1_PER_MT;
-  constexpr int W2F = NHID >= 2 ? MTB * MTA * 4 * kFragGroupFloats : 0;
-  constexpr int W3F = NHID >= 3 ? MTC * MTB * 4 * kFragGroupFloats : 0;
+  constexpr int W2F = NHID >= 2 ? MTB * MTA * KTF : 0;
+  constexpr int W3F = NHID >= 3 ? MTC * MTB * KTF : 0;
   constexpr int HIDF = W1F + W2F + W3F;
   constexpr int KT_OUT = NHID == 1 ? MTA : (NHID == 2 ? MTB : MTC);
   constexpr int B1OFF = HIDF;
@@ -294,11 +326,11 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   constexpr int B3OFF = B2OFF + (NHID >= 2 ? 32 * MTB : 0);
   constexpr int BOOFF = B3OFF + (NHID >= 3 ? 32 * MTC : 0);
 
-  const int out_floats = p.mt_out * KT_OUT * 4 * kFragGroupFloats;
+  const int out_floats = p.mt_out * KT_OUT * KTF;
   const int bias_floats = (BOOFF - HIDF) + 32 * p.mt_out;
   const int lds_out = BOOFF + 32 * p.mt_out;  // output groups (if resident)
   // one 32-bit work counter behind the packed network (decode_plan reserves it)
-  const int out_lds_floats = p.out_lds_tiles * KT_OUT * 4 * kFragGroupFloats;  // resident part of the class layer
+  const int out_lds_floats = p.out_lds_tiles * KT_OUT * KTF;  // resident part of the class layer
   unsigned *tile_ctr = reinterpret_cast<unsigned *>(lds + lds_out + out_lds_floats);
   unsigned *bin_ctr = tile_ctr + 4;  // [kMaxBins][4] u32, used only when n_bins > 1
   if (threadIdx.x == 0) *tile_ctr = 0u;
@@ -312,7 +344,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   // are contiguous in the packed network: one wave-level global_load_lds_dwordx4 moves one 1 KB group
   // (per-lane source, lane-linear LDS image = the fragment-group layout itself; no VGPRs, no ds_write).
   constexpr int RT = ring_tiles_per_slot(PREC, KT_OUT);
-  constexpr int GPT = KT_OUT * 4;                    // fragment groups per class tile (both precisions)
+  constexpr int GPT = KT_OUT * KTF / kFragGroupFloats;  // fragment groups per class tile
   constexpr int GPS = RT * GPT;                      // groups per ring slot
   constexpr int SLOT_FLOATS = GPS * kFragGroupFloats;
   float *const ring = keep_base + (KEEP_LDS ? NT * 16 : 0);
@@ -423,6 +455,14 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       if constexpr (PREC == kPrecF16x3) {
 #pragma unroll
         for (int s = 0; s < KS1; ++s) split8(xr + 8 * s, xhi[s], xlo[s]);
+      } else if constexpr (PREC == kPrecF16) {
+#pragma unroll
+        for (int s = 0; s < KS1; ++s)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x2 x = {xr[8 * s + 2 * q], xr[8 * s + 2 * q + 1]};
+            xhi[s][q] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+          }
       }
       auto layer1_tile = [&](int mt) -> f32x16 {
         f32x16 acc = init_acc(lds + B1OFF + 32 * mt, half);
@@ -433,7 +473,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = mfma32(a[e], xr[4 * g + e], acc);
           }
-        } else {
+        } else if constexpr (PREC == kPrecF16x3) {
 #pragma unroll
           for (int s = 0; s < KS1; ++s) {
             const float *wb = lds + mt * L1_PER_MT + s * 2 * kFragGroupFloats + lo;
@@ -443,6 +483,10 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
             acc = mfma16(ahi, xlo[s], acc);
             acc = mfma16(ahi, xhi[s], acc);
           }
+        } else {
+#pragma unroll
+          for (int s = 0; s < KS1; ++s)
+            acc = mfma16(*reinterpret_cast<const u32x4 *>(lds + mt * L1_PER_MT + s * kFragGroupFloats + lo), xhi[s], acc);
         }
         act16<PREC>(acc);
         return acc;
@@ -462,7 +506,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
           a[0].set(layer1_tile(kt));
 #pragma unroll
           for (int mt = 0; mt < MTB; ++mt)
-            acc2[mt] = dense_tile<PREC, 1>(a, lds + W1F + (mt * MTA + kt) * 4 * kFragGroupFloats + lo, acc2[mt]);
+            acc2[mt] = dense_tile<PREC, 1>(a, lds + W1F + (mt * MTA + kt) * KTF + lo, acc2[mt]);
         }
         NNV_STAMP(1);  // layer 1 + layer 2 MFMAs
         if ((!STREAM || !NNV_RING_LATE_X || n_slots == 0) && next_tile < p.n_tiles) fetch_x(next_tile, xn);
@@ -479,7 +523,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #pragma unroll
         for (int mt = 0; mt < MTC; ++mt) {
           f32x16 acc = init_acc(lds + B3OFF + 32 * mt, half);
-          acc = dense_tile<PREC, MTB>(hb, lds + W1F + W2F + mt * MTB * 4 * kFragGroupFloats + lo, acc);
+          acc = dense_tile<PREC, MTB>(hb, lds + W1F + W2F + mt * MTB * KTF + lo, acc);
           act16<PREC>(acc);
           hc[mt].set(acc);
         }
@@ -576,7 +620,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #pragma unroll
         for (int i = 0; i < kGroup; ++i) {
           accs[i] = init_acc(lds + BOOFF + 32 * (mt0 + i), half);
-          accs[i] = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + (mt0 + i) * KT_OUT * 4 * kFragGroupFloats + lo, accs[i]);
+          accs[i] = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + (mt0 + i) * KT_OUT * KTF + lo, accs[i]);
         }
 #pragma unroll
         for (int i = 0; i < kGroup; ++i) argmax_tile(accs[i], mt0 + i);
@@ -587,7 +631,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       const int mt_res = STREAM ? p.out_lds_tiles : p.mt_out;
       for (int mt = mt0; mt < mt_res; ++mt) {
         f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
-        acc = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + mt * KT_OUT * 4 * kFragGroupFloats + lo, acc);
+        acc = dense_tile<PREC, KT_OUT>(hlast, lds + lds_out + mt * KT_OUT * KTF + lo, acc);
         finish_class_tile(acc, mt);
       }
     }
@@ -686,7 +730,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         int ti = 0;
         for (int mt = 0; mt < p.mt_out; ++mt) {
           f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
-          acc = dense_tile<PREC, KT_OUT>(hlast, p.wpack + HIDF + static_cast<int64_t>(mt) * KT_OUT * 4 * kFragGroupFloats + lo, acc);
+          acc = dense_tile<PREC, KT_OUT>(hlast, p.wpack + HIDF + static_cast<int64_t>(mt) * KT_OUT * KTF + lo, acc);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int ci = 32 * mt + 4 * half + 8 * (r >> 2) + (r & 3);
@@ -827,6 +871,8 @@ extern const KernelEntry kKernelsF16x3[] = {
     NNV_K(kPrecF16x3, 2, 1, 4, 1, 1, 768, false), NNV_K(kPrecF16x3, 2, 2, 4, 2, 1, 768, false),
     NNV_K(kPrecF16x3, 2, 3, 4, 2, 1, 768, false), NNV_K(kPrecF16x3, 4, 1, 4, 1, 1, 768, false),
     NNV_K(kPrecF16x3, 4, 2, 4, 2, 1, 768, false), NNV_K(kPrecF16x3, 4, 3, 4, 2, 1, 768, false),
+    // single-product f16 mode: same geometry (layer-1 k-steps = ceil(G1 / 2))
+    NNV_FAMILY(kPrecF16, 2), NNV_FAMILY(kPrecF16, 4),
 #ifdef NNV_DIAG
     NNV_K(kPrecF16x3, 2, 3, 4, 2, 1, 256, false),
 #endif

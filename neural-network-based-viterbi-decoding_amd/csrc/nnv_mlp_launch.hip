@@ -27,7 +27,7 @@ const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act, bool lean
   const int mtb = s.nhid >= 2 ? s.mt[1] : 1;
   const int mtc = s.nhid >= 3 ? s.mt[2] : 1;
   const int variant = (act || s.streams != 0) ? kVarStream : (lean ? kVarLean : kVarGeneral);
-  const KernelEntry *tab = s.precision == kPrecF32 ? kKernelsF32 : kKernelsF16x3;
+  const KernelEntry *tab = s.precision == kPrecF32 ? kKernelsF32 : kKernelsF16x3;  // second table: both 16-bit modes
   const int n = s.precision == kPrecF32 ? kNumKernelsF32 : kNumKernelsF16x3;
   for (int i = 0; i < n; ++i) {
     const KernelEntry &k = tab[i];
@@ -64,7 +64,7 @@ int pick_threads_impl(const PackedShape &s) {
 int64_t keep_slot_bytes(int threads) { return kKeepLds ? static_cast<int64_t>(threads) * 64 : 0; }
 // two ring slots of RT class tiles each; must match RT / GPS / SLOT_FLOATS in mlp_decode_kernel
 int64_t ring_bytes(const PackedShape &s) {
-  return 2LL * ring_tiles_per_slot(s.precision, s.kt_out) * s.kt_out * 4 * kFragGroupFloats * 4;
+  return 2LL * ring_tiles_per_slot(s.precision, s.kt_out) * class_tile_kb(s.precision, s.kt_out) * 1024;
 }
 
 }  // namespace
@@ -108,7 +108,7 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
   const int64_t scratch = keep_slot_bytes(threads) + (s.streams ? ring_bytes(s) : 0);
   if (base_floats * 4 + kLdsTailBytes + scratch > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
   // as many class-layer M-tiles as fit stay in LDS; the remaining ones go through the ring
-  const int64_t per_tile_bytes = static_cast<int64_t>(s.kt_out) * 4 * kFragGroupFloats * 4;
+  const int64_t per_tile_bytes = static_cast<int64_t>(class_tile_kb(s.precision, s.kt_out)) * 1024;
   int64_t fit = (lds_limit - kLdsTailBytes - scratch - base_floats * 4) / per_tile_bytes;
   if (fit > s.mt_out) fit = s.mt_out;
   if (s.streams == 0 && fit < s.mt_out) return NNV_ERR_UNSUPPORTED_SHAPE;  // decode_configure sized it
