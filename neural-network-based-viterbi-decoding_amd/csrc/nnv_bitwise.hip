@@ -113,6 +113,18 @@ int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, 
   p.ldc = 0;
   p.bn = h->bn;
   p.nblk_m = h->mpad / h->bn;
+  // Column blocks per W slab kept in an XCD's L2: 4 x 128 columns x kpad floats = 2.2 MB at the reference's 1036
+  // inputs.  Measured L2 <- fabric bytes per launch (FETCH_SIZE x 2, 300 k rows x 512 positions, profiles/r03/
+  // bank_tile_order.json): row-block-major (round 2) 168 GB; groups of 2 / 3 / 4 / 5 / 6 / 8 / 16 / 32 column blocks
+  // 93 / 74 / 61 / 63 / 62 / 61 / 92 / 168 GB -- A is re-read once per group ((128 / G) x 1.24 GB), and from G = 5 on
+  // the slab no longer stays resident beside the streaming rows (4 MB of L2 per XCD).  Launch time is the same
+  // for every order (78.0-78.5 ms: the fp32 matrix pipe is the limiter, 0.78 of peak).  NNV_BANK_GROUP overrides
+  // (tuning only; 0 = the round-2 order).
+  static const int forced_group = [] { const char *e = getenv("NNV_BANK_GROUP"); return e ? atoi(e) : -1; }();
+  const int64_t slab_bytes = static_cast<int64_t>(h->bn) * h->kpad * 4;
+  int group = forced_group >= 0 ? forced_group : static_cast<int>((2400LL * 1024) / slab_bytes);
+  if (group > p.nblk_m) group = p.nblk_m;
+  p.col_group = (p.nblk_m > 8 && group >= 2) ? group : 0;
   p.nblk_rows = (n_rows + nnv::kDenseBM - 1) / nnv::kDenseBM;
   p.act = 2;
   p.n_pos = h->n_pos;

@@ -72,8 +72,28 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
   const int64_t blk = blockIdx.x;
   const int xcd = static_cast<int>(blk & 7);
   const int64_t slot = blk >> 3;
-  const int col_blk = static_cast<int>(slot % p.nblk_m);
-  const int64_t row_blk = (slot / p.nblk_m) * 8 + xcd;
+  int col_blk;
+  int64_t row_blk;
+  if (HEAD && p.col_group > 0) {
+    // Bit-wise bank: MANY column blocks (128 for 512 positions: a 68 MB stacked first layer) against a
+    // small A row block (0.5 MB).  Walking all column blocks per row block re-streams W once per row
+    // block (168 GB fetched per launch, PMC round 2).  Instead an XCD takes the column blocks in groups
+    // of `col_group` (W slab of col_group x 0.54 MB, L2 resident) and walks its ROW blocks fastest
+    // inside a group: W is fetched once per group and XCD, A once per group (its col_group blocks are
+    // consecutive slots, so they run together and share the rows in L2).
+    const int64_t n_r8 = (p.nblk_rows + 7) / 8;                  // row blocks per XCD (grid padded)
+    const int64_t per_group = n_r8 * p.col_group;
+    const int groups = (p.nblk_m + p.col_group - 1) / p.col_group;
+    int64_t g = slot / per_group;
+    if (g > groups - 1) g = groups - 1;                           // the last, smaller group
+    const int gsz = g == groups - 1 ? p.nblk_m - static_cast<int>(g) * p.col_group : p.col_group;
+    const int64_t rem = slot - g * per_group;
+    col_blk = static_cast<int>(g) * p.col_group + static_cast<int>(rem % gsz);
+    row_blk = (rem / gsz) * 8 + xcd;
+  } else {
+    col_blk = static_cast<int>(slot % p.nblk_m);
+    row_blk = (slot / p.nblk_m) * 8 + xcd;
+  }
   if (row_blk >= p.nblk_rows) return;  // grid is padded to a multiple of 8 row blocks
   const int64_t row0 = row_blk * kBM;
   const int col0 = col_blk * kBN;

@@ -223,6 +223,7 @@ struct DenseParams {
   int64_t nblk_rows;     // ceil(n_rows / 128)
   int32_t act;           // 1 tanh, 2 relu
   int32_t bn;            // output columns per block: 128, or 32 for narrow layers
+  int32_t col_group;     // bitwise_launch: column blocks per L2-resident W slab (0: row-block-major tile order)
   // fused per-position head (bitwise_launch only): column block c holds positions (bn/32) c ..
   int64_t n_pos;               // bit positions (networks) in the bank
   const float *head_w;         // [n_pos][32][2] fp32, rows >= n_hidden zero
