@@ -18,6 +18,11 @@
 // threads up (the CPU share's path to DRAM carries source read + staging write + DMA read).  Handing
 // the caller's pageable rows to hipMemcpyAsync chunk by chunk instead (the runtime pins and unpins
 // each chunk in place) ran at 61-71 M blocks/s in the same harness, so the staged ring stays.
+// Round 3 probed the remaining route, page-locking the caller's own pages ahead of the DMA
+// (tools/host_register_probe.py, profiles/r03/host_register_probe.json): hipHostRegister itself is lazy on
+// this driver (>400 GB/s "registered"), and the FIRST DMA out of freshly registered pageable pages moves
+// 21.8 GB/s (a second pass over the same pages 54.9, hipHostMalloc memory 56.3): every call presents fresh
+// pages, so zero-copy cannot beat the 44-49 GB/s of the staged ring.
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -98,11 +103,14 @@ class Pool {
 };
 
 int default_threads() {
-  int n = static_cast<int>(std::thread::hardware_concurrency());
-  cpu_set_t set;
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, CPU_COUNT(&set));
-  if (const char *e = getenv("NNV_HOST_THREADS")) n = atoi(e);
-  return std::max(1, std::min(n, 8));   // 8 staging threads saturate the host DRAM beside the DMA engine
+  static const int cached = [] {   // the environment and the affinity mask are read once per process
+    int n = static_cast<int>(std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, CPU_COUNT(&set));
+    if (const char *e = getenv("NNV_HOST_THREADS")) n = atoi(e);
+    return std::max(1, std::min(n, 8));   // 8 staging threads saturate the host DRAM beside the DMA engine
+  }();
+  return cached;
 }
 
 // pageable -> pinned copy with non-temporal stores.  glibc's memcpy switches to streaming stores only
@@ -154,8 +162,21 @@ struct HostPathCtx {
   int32_t *dl[kSlots] = {};
   int32_t *dc[kSlots] = {};
   unsigned long long *dcnt = nullptr;
+  // the staging threads live as long as the handle (a pool per call made thread creation the
+  // dominant cost of the reference's small test sets); rebuilt only when another thread count is asked for
+  Pool *pool = nullptr;
+  Pool *pool_for(int threads) {
+    if (pool && pool->size() != threads) {
+      delete pool;
+      pool = nullptr;
+    }
+    if (!pool) pool = new (std::nothrow) Pool(threads);
+    return pool;
+  }
 
   void release() {
+    delete pool;
+    pool = nullptr;
     for (int s = 0; s < kSlots; ++s) {
       if (px[s]) (void)hipHostFree(px[s]);
       if (pl[s]) (void)hipHostFree(pl[s]);
@@ -255,11 +276,18 @@ extern "C" int32_t nnv_mlp_decode_host_f32(nnv_mlp_handle *h, const float *x_hos
     const nnv_status st = c.ensure(m, n_in, labels);
     if (st != NNV_OK) return st;
   }
-  nnv::Pool pool(n_threads > 0 ? std::min(n_threads, 64) : nnv::default_threads());
-  const int T = pool.size();
+  // a call that fits one stage is copied by the calling thread alone: no hand-off to the staging threads
+  const int64_t n_chunks = (n_rows + m - 1) / m;
+  const int want_threads = n_chunks == 1 ? 1 : (n_threads > 0 ? std::min(n_threads, 64) : nnv::default_threads());
+  nnv::Pool *const pool_ptr = want_threads > 1 ? c.pool_for(want_threads) : nullptr;
+  if (want_threads > 1 && !pool_ptr) return NNV_ERR_OUT_OF_MEMORY;
+  const int T = want_threads;
+  auto run_on_threads = [&](const std::function<void(int)> &f) {
+    if (pool_ptr) pool_ptr->run(f);
+    else f(0);
+  };
   if (hipMemsetAsync(c.dcnt, 0, 4 * sizeof(unsigned long long), c.s_cmp) != hipSuccess) return NNV_ERR_HIP;
 
-  const int64_t n_chunks = (n_rows + m - 1) / m;
   int32_t status = NNV_OK;
   auto chunk_span = [&](int64_t i, int64_t *lo, int64_t *cnt) {
     *lo = i * m;
@@ -276,7 +304,7 @@ extern "C" int32_t nnv_mlp_decode_host_f32(nnv_mlp_handle *h, const float *x_hos
     }
     if (!cls32_host && !cls64_host) return;
     const int32_t *src = c.pc[s];
-    pool.run([&](int t) {
+    run_on_threads([&](int t) {
       int64_t a, b;
       nnv::split(cnt, T, t, 16, &a, &b);
       if (cls32_host && b > a) memcpy(cls32_host + lo + a, src + a, (b - a) * sizeof(int32_t));
@@ -292,7 +320,7 @@ extern "C" int32_t nnv_mlp_decode_host_f32(nnv_mlp_handle *h, const float *x_hos
     if (i >= kSlots) drain(i - kSlots);  // slot s is free once its previous classes are with the caller
     if (status != NNV_OK) break;
     // pageable -> pinned, T threads (16-float = 64-byte aligned slices)
-    pool.run([&](int t) {
+    run_on_threads([&](int t) {
       int64_t a, b;
       nnv::split(cnt * n_in, T, t, 16, &a, &b);
       if (b > a) nnv::stream_copy(c.px[s] + a, x_host + lo * n_in + a, (b - a) * sizeof(float));

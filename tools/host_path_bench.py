@@ -30,12 +30,21 @@ for threads in (0, 4, 16):
                      "GB_per_s_moved": n * 68 / best / 1e9, "bit_exact": ok})
         print(f"threads {threads:2d} chunk {chunk:>8d}: {best*1e3:8.1f} ms  {blocks/best/1e6:7.1f} M blocks/s  "
               f"{n*68/best/1e9:6.1f} GB/s moved  match={ok}", file=sys.stderr)
+# small test sets (the reference's own sizes: 2 k rows = BASELINE configs[0]; 64 k rows): latency of ONE host call
+small = {}
+for m in (2_000, 65_536):
+    net.decode_host(x[:m], lab[:m], 8)
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter(); net.decode_host(x[:m], lab[:m], 8); ts.append(time.perf_counter() - t0)
+    small[str(m)] = {"rows": m, "median_us_per_call": float(np.median(ts) * 1e6), "min_us_per_call": float(min(ts) * 1e6)}
+    print(f"host call over {m} rows: median {np.median(ts)*1e6:.0f} us, min {min(ts)*1e6:.0f} us", file=sys.stderr)
 t0 = time.perf_counter(); t = torch.from_numpy(x).cuda(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 px = torch.from_numpy(x[: 1 << 24]).pin_memory()
 t2 = torch.empty_like(px, device="cuda"); t2.copy_(px, non_blocking=True); torch.cuda.synchronize()     # warm: allocation, first touch
 t0 = time.perf_counter(); t2.copy_(px, non_blocking=True); torch.cuda.synchronize(); dtp = time.perf_counter() - t0
 best = max(rows, key=lambda r: r["M_blocks_per_s"])
 print(json.dumps({"metric": "host-array decode, PCIe inclusive (BASELINE configs[2] rows, host in / host out)",
-                  "blocks": blocks, "best": best, "all": rows,
+                  "blocks": blocks, "best": best, "all": rows, "small_batch_latency": small,
                   "plain_pageable_h2d_GBps": x.nbytes / dt / 1e9, "pinned_h2d_GBps": px.numel() * 4 / dtp / 1e9,
                   "link_bound_M_blocks_per_s": px.numel() * 4 / dtp / 544 / 1e6}))
