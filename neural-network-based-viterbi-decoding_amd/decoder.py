@@ -552,17 +552,22 @@ def generate_awgn_blocks(code: str, tile_bits: int, n_rows: int, sigma, seed: in
 #          the reference's own call is a CPU call, src/fnn_viterbi.py:606-610)
 # ---------------------------------------------------------------------------
 class _PackEntry:
-    __slots__ = ("net", "refs", "stamps")
+    __slots__ = ("net", "refs", "versions")
 
-    def __init__(self, net, refs, stamps):
-        self.net, self.refs, self.stamps = net, refs, stamps
+    def __init__(self, net, refs, versions):
+        self.net, self.refs, self.versions = net, refs, versions
 
 
-# key: (device, precision, id of every weight/bias tensor object).  An entry is valid only while
-# every one of those tensor OBJECTS is still alive and unmodified: it holds a weakref to each (a
-# dead tensor evicts the entry from the weakref callback, which also frees the packed network's
-# HBM) plus its (data_ptr, _version) at pack time.  Raw addresses alone are not a key: the caching
-# allocator hands a freed address to the next same-sized checkpoint with _version 0 again.
+# key: (device, precision, per tensor: identity of its STORAGE + offset / shape / stride).  Keying on the
+# storage rather than on the tensor object makes the common idioms hit: ``[w.detach() for w in ws]``,
+# ``.data``, a view of a live parameter -- new tensor objects every call, the same storage and the same
+# version counter (round 2 keyed on ``id(tensor)``: every such call re-packed, hipMalloc + H2D + a synchronising
+# hipFree, an order of magnitude slower than the decode it wrapped).  An entry is valid only while every one
+# of those storages is still ALIVE and unmodified: it holds a weak reference to each StorageImpl (which also
+# keeps that address from being handed to another storage, so a freed-and-reloaded checkpoint at the same
+# data_ptr with _version 0 again cannot hit a stale entry) plus the version counters at pack time.
+# Nothing is freed from a weakref callback (a hipFree from the garbage collector, at an arbitrary point of
+# another op call): dead entries are dropped at the next call of ``_cached_pack``.
 _PACK_CACHE: "collections.OrderedDict[tuple, _PackEntry]" = collections.OrderedDict()
 _PACK_CACHE_MAX = 16
 
@@ -580,22 +585,30 @@ def clear_pack_cache() -> None:
         _evict(key)
 
 
+def _sweep_dead_entries() -> None:
+    for key in [k for k, e in _PACK_CACHE.items() if any(r.expired() for r in e.refs)]:
+        _evict(key)
+
+
 def _cached_pack(weights: List[torch.Tensor], biases: List[torch.Tensor], device) -> PackedMLP:
+    from torch.multiprocessing.reductions import StorageWeakRef
     tensors = list(weights) + list(biases)
     precision = _resolve_precision(None)
-    key = (str(device), precision) + tuple(id(t) for t in tensors)
-    stamps = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    _sweep_dead_entries()
+    storages = [t.untyped_storage() for t in tensors]
+    key = (str(device), precision) + tuple(
+        (st._cdata, t.storage_offset(), tuple(t.shape), tuple(t.stride()), str(t.dtype)) for st, t in zip(storages, tensors))
+    versions = tuple(t._version for t in tensors)
     e = _PACK_CACHE.get(key)
     if e is not None:
-        if e.stamps == stamps and all(r() is t for r, t in zip(e.refs, tensors)):
+        if e.versions == versions:
             _PACK_CACHE.move_to_end(key)
             return e.net
-        _evict(key)                                   # same ids, other tensors / modified in place
+        _evict(key)                                   # same storages, modified in place since
     while len(_PACK_CACHE) >= _PACK_CACHE_MAX:
         _evict(next(iter(_PACK_CACHE)))               # least recently used
     net = PackedMLP(weights, biases, device=device, precision=precision)
-    refs = [weakref.ref(t, lambda _r, k=key: _evict(k)) for t in tensors]
-    _PACK_CACHE[key] = _PackEntry(net, refs, stamps)
+    _PACK_CACHE[key] = _PackEntry(net, [StorageWeakRef(st) for st in storages], versions)
     return net
 
 

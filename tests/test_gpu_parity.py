@@ -89,6 +89,8 @@ SHAPES = [
     ([16, 128, 256], 8),             # 1 hidden layer
     ([16, 100, 50, 20, 256], 8),     # hidden widths that are not multiples of 32
     ([24, 128, 64, 32, 4096], 12),   # widest supported input, 4096 classes
+    ([18, 128, 64, 32, 512], 9),     # 120 KB packed: fits the LDS alone, not beside 1024 threads' winner slots
+                                     # (the resident / ring-swept decision is taken with the workgroup size)
 ]
 
 

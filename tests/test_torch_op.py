@@ -99,13 +99,20 @@ def test_pack_cache_follows_the_tensors_not_their_addresses(fake_pack):
     Wa, ba = _weights(1.0)
     n1 = decoder._cached_pack(Wa, ba, "cpu")
     assert decoder._cached_pack(Wa, ba, "cpu") is n1 and len(fake_pack.made) == 1      # hit
+    # the idioms that make NEW tensor objects over the same storage every call must hit
+    assert decoder._cached_pack([w.detach() for w in Wa], [v.detach() for v in ba], "cpu") is n1
+    assert decoder._cached_pack([w.data for w in Wa], [v.view(-1) for v in ba], "cpu") is n1
+    assert len(fake_pack.made) == 1
+    assert decoder._cached_pack([Wa[0].t().contiguous().t(), Wa[1]], ba, "cpu") is not n1      # another storage
     ptrs = [t.data_ptr() for t in Wa + ba]
     del Wa, ba
     gc.collect()
-    assert n1.closed and len(decoder._PACK_CACHE) == 0       # dead tensors evict + free the packed copy
+    assert not n1.closed                                     # nothing is freed from the garbage collector ...
     # a new checkpoint of the same shapes, very likely at the same addresses with _version 0 again
     Wb, bb = _weights(2.0)
     n2 = decoder._cached_pack(Wb, bb, "cpu")
+    assert n1.closed                                         # ... dead entries go at the next call
+    assert all(not any(r.expired() for r in e.refs) for e in decoder._PACK_CACHE.values())
     assert n2 is not n1 and n2.tag == 2.0
     if [t.data_ptr() for t in Wb + bb] == ptrs:
         assert all(t._version == 0 for t in bb)              # the case the old (ptr, version) key got wrong
