@@ -177,4 +177,6 @@ def test_reloaded_checkpoint_is_not_decoded_with_the_old_network(cuda_device):
         del Wd, bd
         gc.collect()
     assert (results[0] != results[1]).float().mean() > 0.5
+    assert len(decoder._PACK_CACHE) == 1        # the first checkpoint's entry went when the second was packed;
+    decoder._sweep_dead_entries()               # the second one's goes at the next call (never from the GC)
     assert len(decoder._PACK_CACHE) == 0
