@@ -376,7 +376,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     k = __builtin_amdgcn_readfirstlane(k);
     return static_cast<int64_t>(blockIdx.x) + static_cast<int64_t>(k) * gridDim.x;
   };
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // a scalar: branches on it are uniform
   // Stream variant: the waves of a workgroup sweep the streamed class tiles in lock step (one barrier per
   // ring slot), so tiles are dealt per ROUND instead: in round r wave v takes the workgroup's tile r NW + v
   // (workgroup w owns tiles w, w + G, ...), every wave runs the same number of rounds and ring phases, and

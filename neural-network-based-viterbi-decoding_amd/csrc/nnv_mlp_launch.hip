@@ -62,7 +62,7 @@ int pick_threads_impl(const PackedShape &s) {
 
 
 int64_t keep_slot_bytes(int threads) { return kKeepLds ? static_cast<int64_t>(threads) * 64 : 0; }
-// two ring slots of RT class tiles each; must match RT / GPS / SLOT_FLOATS in mlp_decode_kernel
+// two ring buffers of RT class tiles each; must match RT / GPS / SLOT_FLOATS in mlp_decode_kernel
 int64_t ring_bytes(const PackedShape &s) {
   return 2LL * ring_tiles_per_slot(s.precision, s.kt_out) * class_tile_kb(s.precision, s.kt_out) * 1024;
 }
@@ -93,7 +93,12 @@ int decode_configure(PackedShape *s, int lds_limit) {
   const int t = pick_threads_impl(*s);
   if (whole + keep_slot_bytes(t) <= lds_limit) return t;
   s->streams = 1;
-  return pick_threads_impl(*s);
+  // ring-swept: hidden layers + biases + winner slots + ring must fit; a network with a very large class
+  // layer's biases (4096 classes: 16 KB) falls back to 512 threads (half the winner slots)
+  int ts = pick_threads_impl(*s);
+  const int64_t fixed = (s->hid_floats + s->bias_floats) * 4 + kLdsTailBytes + ring_bytes(*s);
+  if (fixed + keep_slot_bytes(ts) > lds_limit && ts > 512 && fixed + keep_slot_bytes(512) <= lds_limit) ts = 512;
+  return ts;
 }
 
 nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
