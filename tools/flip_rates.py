@@ -12,12 +12,13 @@ networks (tests/golden/forward_fp64.npz, random weights) and on the trained conf
   eigen_tanh_f32  numpy float32 matmul + TensorFlow-1.x's CPU tanh restated (oracle/eigen_tanh.py)
   tf_like_f32     sequential-k, no-FMA float32 matmul (Eigen gebp order) + that tanh, on the first 300 k rows
   hip_f32 / hip_f16x3   the product kernel (only with a GPU)
+  hip_f16     the opt-in single-product 16-bit mode: NOT held to the 1e-5 rules, listed to show what it costs
 
 For every implementation: max |out - fp64|, classes differing from fp64, and the largest fp64 top-2
 margin among those rows (must be < 1e-5: the near-tie rule).  Then the pairwise flip counts.
 PARITY STAYS UNPINNED: TensorFlow's own kernels are not among these.
 
-Usage: python tools/flip_rates.py [--rows N] > profiles/r02/flip_rates.json
+Usage: python tools/flip_rates.py [--rows N] > profiles/r03/flip_rates.json
 """
 import argparse
 import json
@@ -51,7 +52,7 @@ def implementations(x, Ws, bs, b, gpu):
         import nnviterbi_amd  # noqa: F401
         from nnviterbi_amd.decoder import PackedMLP
         xd = torch.from_numpy(x).cuda()
-        for prec in ("f32", "f16x3"):
+        for prec in ("f32", "f16x3", "f16"):   # "f16": the opt-in single-product mode, OUTSIDE the 1e-5 contract (shown for scale)
             net = PackedMLP(Ws, bs, precision=prec)
             cls = net.decode(xd, tile_bits=b)["cls32"].cpu().numpy().astype(np.int64)
             act = net.forward(xd).cpu().numpy()

@@ -3,7 +3,7 @@
 #   tools/run_round_benches.sh r02 [quick]
 # Copy what is to be judged into profiles/<tag>/ afterwards.  Each leg is one python process.
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag
 mkdir -p $out
 run() {  # stdout -> <name>.json (JSON lines only: gloo prints banners on stdout), stderr -> <name>.log
@@ -19,6 +19,7 @@ run host_path python3 tools/host_path_bench.py
 run flip_rates python3 tools/flip_rates.py
 run bench_config4_full_share python3 tools/bench_config4.py --blocks-per-gpu 12500000
 run bench_configs01 python3 tools/bench_configs01.py
+run bench_configs01_random_weights python3 tools/bench_configs01.py --weights random
 run bench_seq_predict python3 tools/bench_seq_predict.py
 run bench_rnn_10M_blocks python3 tools/bench_rnn.py --blocks 10000000 --steps 2
 run bench_batch_sweep python3 tools/bench_batch_sweep.py
