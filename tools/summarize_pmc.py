@@ -90,14 +90,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "--stream":
 root = sys.argv[1]
 out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "pmc_summary.json")
 ROWS = 80_000_000
-acc = {"f32": defaultdict(list), "f16x3": defaultdict(list)}
+acc = {"f32": defaultdict(list), "f16x3": defaultdict(list), "f16": defaultdict(list)}
 for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
             if "mlp_decode_kernel" not in name:
                 continue
-            prec = "f16x3" if "mlp_decode_kernel<1," in name.replace(" ", "") else "f32"
+            flat = name.replace(" ", "")
+            if ",true," in flat:      # the debug forward instantiation (bench.py's small f16-vs-f32 output sample)
+                continue
+            prec = "f16x3" if "mlp_decode_kernel<1," in flat else ("f16" if "mlp_decode_kernel<2," in flat else "f32")
             acc[prec][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {"source_dir": root, "rows_per_launch": ROWS, "tiles_per_launch": ROWS // 32,
            "correction": "gfx950: FETCH_SIZE (KB) counts 64 B per 128-B request of a wide coalesced stream -> x2; "
