@@ -16,7 +16,7 @@ run bench_n1_default python3 bench.py
 NNV_DIST_BACKEND=gloo run bench_2rank_rehearsal_one_gpu python3 bench.py --gpus 2 --blocks-per-gpu 4000000 --steps 5 --warmup 2 --no-cpu-baseline
 run bench_bitwise python3 tools/bench_bitwise.py
 run host_path python3 tools/host_path_bench.py
-run flip_rates python3 tools/flip_rates.py
+echo '== flip_rates'; python3 tools/flip_rates.py > $out/flip_rates.json 2> $out/flip_rates.log || echo '   FAILED'   # indented JSON: not line-filtered
 run bench_config4_full_share python3 tools/bench_config4.py --blocks-per-gpu 12500000
 run bench_configs01 python3 tools/bench_configs01.py
 run bench_configs01_random_weights python3 tools/bench_configs01.py --weights random
