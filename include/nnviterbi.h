@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NNV_ABI_VERSION 2 /* 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device */
+#define NNV_ABI_VERSION 3 /* 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16 */
 #define NNV_MAX_LAYERS 4 /* dense layers incl. the output layer */
 
 typedef enum nnv_status {
