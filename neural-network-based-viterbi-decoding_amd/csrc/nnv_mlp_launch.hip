@@ -53,9 +53,10 @@ int pick_threads_impl(const PackedShape &s) {
     if (!k) continue;
     hipFuncAttributes attr;
     if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) continue;
-    // up to 8 spilled dwords cost less than a wave per SIMD; the stream variant's spills (<= 16 dwords) sit in
-    // per-row-tile code, outside its ring loop (configs[1], same box: 0.846 at 1024 threads, 0.79 at 512)
-    if (attr.localSizeBytes <= (s.streams ? 64u : 32u)) return nt;
+    // up to 8 spilled dwords cost less than a wave per SIMD; the stream variant's spills (fp32 9-12 dwords, f16x3
+    // 31-40) sit in per-row-tile code, outside its ring loop: configs[1], same box, fp32 0.846 at 1024 threads vs
+    // 0.79 at 512 and 0.827 at 768; f16x3 267 M blocks/s at 1024 vs 258 M at 768
+    if (attr.localSizeBytes <= (s.streams ? 128u : 32u)) return nt;
   }
   return 512;
 }
