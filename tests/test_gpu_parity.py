@@ -552,6 +552,34 @@ def test_ring_swept_class_layer_matches_the_oracle_over_many_rounds(cuda_device,
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
+def test_ring_variant_with_every_other_option(cuda_device, precision):
+    """The ring-swept class layer together with the options the benchmark call shape does not use: per-SNR-bin
+    counters (LDS atomics), the int64 / bit-matrix outputs, and the debug forward entry over more than one round of
+    its 8-wave workgroups (70,001 rows x 1,000 classes: a ragged class count AND a ragged last row tile)."""
+    dims, b = [20, 128, 64, 1000], 10
+    Ws, bs = _net(dims, seed=77)
+    n, rpb, n_bins = 70_001, 10, 7
+    rng = np.random.RandomState(3)
+    x = (rng.randn(n, dims[0]) * 1.1).astype(np.float32)
+    labels = rng.randint(0, dims[-1], n).astype(np.int32)
+    net = PackedMLP(Ws, bs, precision=precision)
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    full = net.decode(xd, labels=ld, tile_bits=b, want_cls64=True, want_bits=True)
+    cls = full["cls32"].cpu().numpy()
+    act = net.forward(xd).cpu().numpy()
+    assert act.shape == (n, 1000)
+    _assert_parity(cls, act, x, Ws, bs, b)
+    assert np.array_equal(full["bits"].cpu().numpy(), O.class_to_bits(cls, b))
+    first_row = 123_457
+    binned = net.decode_binned(xd, ld, n_bins, rpb, first_row=first_row, tile_bits=b, want_cls32=True)
+    assert np.array_equal(binned["cls32"].cpu().numpy(), cls)
+    bins = ((first_row + np.arange(n)) // rpb) % n_bins
+    want = np.stack([O.error_counters(cls[bins == k], labels[bins == k], b) for k in range(n_bins)])
+    assert np.array_equal(binned["counters"].cpu().numpy(), want)
+    net.close()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_full_size_round_trip_and_counter_identities(cuda_device, precision):
     """10 M blocks = 80 M rows (the benchmark's per-GPU workload)."""
     b, rows_per_block, n_blocks = 8, 8, 10_000_000
