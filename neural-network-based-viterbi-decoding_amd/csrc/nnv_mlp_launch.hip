@@ -56,7 +56,8 @@ int pick_threads_impl(const PackedShape &s) {
     // up to 8 spilled dwords cost less than a wave per SIMD; the stream variant's spills (fp32 9-12 dwords, f16x3
     // 31-40) sit in per-row-tile code, outside its ring loop: configs[1], same box, fp32 0.846 at 1024 threads vs
     // 0.79 at 512 and 0.827 at 768; f16x3 267 M blocks/s at 1024 vs 258 M at 768
-    if (attr.localSizeBytes <= (s.streams ? 128u : 32u)) return nt;
+    // (1-hidden-layer stream kernels hold 64 activation registers and spill 80-150 dwords at 1024 threads: old rule)
+    if (attr.localSizeBytes <= ((s.streams && s.nhid >= 2) ? 128u : 32u)) return nt;
   }
   return 512;
 }
