@@ -383,8 +383,8 @@ int32_t nnv_mlp_decode_f32_timed(const nnv_mlp_handle *h, const float *x_dev,
  * variant a classes+counters call on aligned rows gets, weights
  * resident in LDS (1/0 for the output layer), rows per wave tile, depth,
  * n_classes}; info_host[8] = precision; info_host[9] = class-layer M-tiles (32
- * classes each) resident in LDS, the rest being streamed from L2 (info_host must
- * hold 10 ints). */
+ * classes each) resident in LDS, the rest being swept by the workgroup through an
+ * LDS ring filled from L2 (info_host must hold 10 ints). */
 int32_t nnv_mlp_launch_info(const nnv_mlp_handle *h, int64_t n_rows,
                             int32_t *info_host);
 

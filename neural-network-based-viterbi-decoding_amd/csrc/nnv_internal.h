@@ -121,7 +121,7 @@ struct DecodeParams {
   int32_t mt_out;
   int32_t n_classes;
   int32_t out_in_lds;  // ALL output-layer groups are LDS resident
-  int32_t out_lds_tiles;  // class-layer M-tiles resident in LDS (the rest is streamed from L2)
+  int32_t out_lds_tiles;  // class-layer M-tiles resident in LDS (the rest goes through the LDS ring)
   int32_t tile_bits;
   const int32_t *labels;
   int32_t *cls32;

@@ -300,7 +300,7 @@ __device__ unsigned long long g_diag[16];
 // VARIANT selects what the instantiation carries besides the arithmetic (cold code in the
 // persistent loop costs issue slots and registers even when it is never taken):
 //   kVarGeneral  every option of the ABI, class layer LDS resident
-//   kVarStream   + non-resident class-layer M-tiles streamed from L2
+//   kVarStream   + non-resident class-layer M-tiles swept by the workgroup through the LDS ring
 //   kVarLean     the benchmark / sweep call shape only: 16-byte aligned rows of an even, 4-divisible
 //                half width (p.xvec), class count a multiple of 32, classes + counters out (no
 //                int64 classes, no bit matrix, no per-SNR bins), class layer resident

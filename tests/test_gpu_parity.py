@@ -82,7 +82,7 @@ def test_golden_forward_fixtures(cuda_device, forward_golden, name, depth, b, pr
 SHAPES = [
     ([16, 128, 64, 32, 256], 8),     # BASELINE configs[2] row shape
     ([14, 128, 64, 32, 128], 7),     # reference default (scalar x loads: 56-byte rows)
-    ([20, 128, 64, 32, 1024], 10),   # configs[0] row shape (output layer streamed from L2)
+    ([20, 128, 64, 32, 1024], 10),   # configs[0] row shape (class layer swept through the LDS ring)
     ([20, 128, 64, 1024], 10),       # configs[1] row shape (2-layer)
     ([12, 128, 64, 32, 64], 6),
     ([6, 128, 64, 32, 8], 3),        # fewer classes than one 32-wide tile
@@ -507,7 +507,7 @@ def matched_filter_network(b, code, n_layers=3):
 def test_baseline_configs_0_and_1_at_full_size(cuda_device, precision, code, b, n_layers, block_len,
                                                n_blocks, snr_db):
     """Tiling rule: b = 10 divides both block lengths; the class layer (1024 classes) does not fit the
-    LDS and is streamed from L2.  Round trip at full size + a bounded oracle sample."""
+    LDS and is swept through the LDS ring.  Round trip at full size + a bounded oracle sample."""
     rpb = block_len // b
     n = n_blocks * rpb
     Ws, bs = matched_filter_network(b, code, n_layers)
