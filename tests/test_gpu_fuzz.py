@@ -73,6 +73,39 @@ def test_fused_decoder_random_shapes(cuda_device, seed, precision):
     net.close()
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("seed", range(6 * SCALE))
+def test_fused_decoder_random_shapes_many_rows(cuda_device, seed, precision):
+    """K1 over SEVERAL rounds of its persistent workgroups (40 k - 150 k rows: every wave of every workgroup decodes
+    more than one row tile, ragged tails), class counts up to 4096 so that the resident, lean and ring-swept variants
+    all occur.  Every row against the C oracle; rows that differ must be float64 near-ties."""
+    rng = np.random.RandomState(5000 + seed)
+    n_hidden = rng.randint(1, 4)
+    n_in = int(2 * rng.randint(1, 13))
+    b = int(rng.randint(3, 13))
+    n_classes = int(2 ** b if rng.rand() < 0.6 else rng.randint(2 ** (b - 1) + 1, 2 ** b + 1))
+    dims = [n_in] + [128, 64, 32][:n_hidden] + [n_classes]
+    n = int(rng.choice([40_003, 70_001, 150_017]))
+    Ws, bs = _net(dims, rng)
+    x = (rng.randn(n, n_in) * 1.3).astype(np.float32)
+    labels = rng.randint(0, n_classes, size=n).astype(np.int32)
+    try:
+        net = PackedMLP(Ws, bs, precision=precision)
+    except nnviterbi_amd.NNViterbiError:
+        pytest.skip("no instantiation for this shape (1 hidden layer x thousands of classes)")
+    r = net.decode(torch.from_numpy(x).cuda(), labels=torch.from_numpy(labels).cuda(), tile_bits=b)
+    cls = r["cls32"].cpu().numpy()
+    ref = O.decode_c(x, Ws, bs, b, labels=labels, want_bits=False)
+    diff = np.flatnonzero(cls != ref["cls"])
+    assert len(diff) <= 10
+    if len(diff):
+        o64 = O.forward(x[diff], Ws, bs, np.float64)
+        bad = cls[diff] != O.argmax_first(o64)
+        assert not bad.any() or O.top2_margin(o64)[bad].max() < TOL
+    assert np.array_equal(r["counters"].cpu().numpy(), O.error_counters(cls, labels, b))
+    net.close()
+
+
 @pytest.mark.parametrize("seed", range(8 * SCALE))
 def test_bitwise_bank_random_shapes(cuda_device, seed):
     """K4b: random input width (even), hidden width <= 32, 1..40 positions, ragged rows."""
