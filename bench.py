@@ -131,8 +131,9 @@ def cpu_baseline(x_dev, labels_dev, Ws, bs, hip_cls, budget_s=12.0, torch_budget
     }
 
 
-def other_baseline_configs(dev, steps: int):
-    """BASELINE configs[0] and configs[1] measured in the same run (never `value`): (7,5) K=3 at block_len 20 / 100 as
+def other_baseline_configs(dev, steps: int, net_headline):
+    """The other four BASELINE configs measured in the same run (never `value`; 3 and 4 at reduced size, labelled).
+    configs[0] and configs[1]: (7,5) K=3 at block_len 20 / 100 as
     b = 10 tiles, network 20-128-64(-32)-1024 -- the 1024-class layer does not fit the LDS and is swept by each
     workgroup through an LDS ring (K1's stream variant).  Matched-filter weights of the reference's
     architecture (pass-through hidden layers, class layer = correlation with every codeword), so that the BER is the
@@ -168,6 +169,51 @@ def other_baseline_configs(dev, steps: int):
                      "ber": float(c[0] / c[2]), "roofline_frac_of_fp32_mfma_peak": tf / MFMA_PEAK_TFLOPS["f32"],
                      "class_tiles_in_lds": netm.launch_info(n)["class_tiles_in_lds"], "class_tiles": dims[-1] // 32}
         netm.close()
+    # configs[3]: (133,171) block_len=1024 = 128 tiles of b=8, block i at SNR (i mod 7) dB; on-device generation
+    # INCLUDED, per-SNR-bin counters.  BASELINE names 100 M blocks over 8 GPUs (12.5 M per GPU: that share is the
+    # `-m gpu` test test_mixed_snr_sweep_full_per_gpu_share); here a reduced share, labelled so.
+    n3 = 400_000
+    sig = [float(fv.DecoderConfig(snr_db=float(d)).sigma) for d in range(7)]
+    nd.decode_blocks_sharded(net_headline, "133171", TILE_BITS, 7 * 64, 128, sig, 1, 0, 1, chunk_rows=1 << 20, device=dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    c3 = nd.decode_blocks_sharded(net_headline, "133171", TILE_BITS, n3, 128, sig, 2024, 0, 1, chunk_rows=1 << 25, device=dev)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    c3 = c3.cpu().numpy()
+    out["configs[3]"] = {"workload": f"REDUCED: {n3} blocks on one GPU (BASELINE: 100M over 8 GPUs) -- (133,171) block_len=1024 as "
+                                     f"128 tiles of b=8, SNR of block i = i mod 7 dB, generation included, per-SNR-bin counters",
+                         "value": n3 / dt, "unit": "blocks/s", "seconds": dt, "dtype": "f32",
+                         "ber_by_snr_db": {str(d): float(c3[d, 0] / c3[d, 2]) for d in range(7)}}
+    # configs[4]: the recurrent decoder forward.  BASELINE says GRU; the reference builds an LSTM(20) seq2seq
+    # (src/rnn_viterbi.py:289-318), and that is what runs.  1 M of the 10 M blocks (the full size is a `-m gpu` test).
+    from nnviterbi_amd import rnn_viterbi as rv
+    from nnviterbi_amd.decoder import Seq2SeqLSTM
+    L, B4 = 256, 1_000_000
+    cfg4 = rv.RNNDecoderConfig(block_length=L, encoder_hidden_units=20)
+    lstm = Seq2SeqLSTM(rv.initialize_parameters(cfg4, rng=np.random.RandomState(7)), device=dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    enc = torch.trunc(torch.sign(torch.randn((2 * L, B4), device=dev, generator=g))
+                      + float(cfg4.sigma_vec[cfg4.test_snr_index]) * torch.randn((2 * L, B4), device=dev, generator=g))
+    dec = torch.zeros((2 * L, B4), device=dev)
+    dec[0] = 1.0
+    dec[1:L + 1] = torch.sign(torch.randn((L, B4), device=dev, generator=g))
+    lstm.forward(enc, dec)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(2):
+        r4 = lstm.forward(enc, dec)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms4 = e0.elapsed_time(e1) / 2
+    flop4 = 2 * (2 * L) * 2 * (1 + 20) * 4 * 20 + 2 * (2 * L) * 20
+    out["configs[4]"] = {"workload": f"REDUCED: {B4} of BASELINE's 10M blocks -- recurrent decoder forward, LSTM(20) seq2seq "
+                                     f"(BASELINE says GRU; the reference builds an LSTM), (133,171) block_len={L}, untrained weights",
+                         "value": B4 / (ms4 * 1e-3), "unit": "blocks/s", "ms_per_launch": ms4, "dtype": "f32",
+                         "roofline_frac_of_fp32_mfma_peak": flop4 * B4 / (ms4 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f32"],
+                         "logits_finite": bool(torch.isfinite(r4["logits"]).all().item())}
+    lstm.close()
     return out
 
 
@@ -487,7 +533,7 @@ def main():
                     "(tests/test_gpu_f16_mode.py states its own tolerance); BASELINE's bar for it is |dBER| <= 1e-4",
         }
         if world == 1:
-            out["other_baseline_configs"] = other_baseline_configs(dev, max(3, args.steps // 2))
+            out["other_baseline_configs"] = other_baseline_configs(dev, max(3, args.steps // 2), net)
         if world == 1 and not args.no_cpu_baseline:
             base, parity = cpu_baseline(x, labels, Ws, bs, cls)
             out["cpu_baseline"] = base
