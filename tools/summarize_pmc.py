@@ -98,7 +98,10 @@ for path in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv
             if "mlp_decode_kernel" not in name:
                 continue
             flat = name.replace(" ", "")
-            if ",true," in flat:      # the debug forward instantiation (bench.py's small f16-vs-f32 output sample)
+            # only the headline launches: the LEAN instantiation (last template argument 2) over the configs[2]
+            # rows.  bench.py also runs the debug forward (",true,": its f16-vs-f32 output sample), the stream
+            # variant (configs[0]/[1]) and the general one (configs[3], per-SNR bins) for `other_baseline_configs`.
+            if not flat.split("(")[0].endswith(",false,2>"):
                 continue
             prec = "f16x3" if "mlp_decode_kernel<1," in flat else ("f16" if "mlp_decode_kernel<2," in flat else "f32")
             acc[prec][r["Counter_Name"]].append(float(r["Counter_Value"]))
