@@ -47,7 +47,7 @@ for name, block_len, n_blocks, n_layers, snr_db in (("configs[0]", 20, 1_000, 3,
     out = {"metric": f"decoded blocks/sec, (7,5) block_len={block_len} @ SNR {snr_db} dB, {n_layers}-layer FNN",
            "config": name, "weights": args.weights, "blocks": n_blocks, "rows_per_block": rpb, "net": dims, "unit": "blocks/s"}
     flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
-    for prec in ("f32", "f16x3"):
+    for prec in ("f32", "f16x3", "f16"):      # "f16": the opt-in single-product mode, outside the 1e-5 contract
         net = PackedMLP(Ws, bs, precision=prec)
         cls = torch.empty(n, dtype=torch.int32, device="cuda")
         cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
