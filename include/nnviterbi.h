@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NNV_ABI_VERSION 3 /* 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16 */
+#define NNV_ABI_VERSION 4 /* 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex */
 #define NNV_MAX_LAYERS 4 /* dense layers incl. the output layer */
 
 typedef enum nnv_status {
@@ -292,6 +292,10 @@ typedef struct nnv_bitwise_desc {
 typedef struct nnv_bitwise_handle nnv_bitwise_handle;
 
 int32_t nnv_bitwise_prepack(const nnv_bitwise_desc *net, nnv_bitwise_handle **out);
+/* precision: NNV_PRECISION_F32 (= nnv_bitwise_prepack) or NNV_PRECISION_F16X3 (the stacked first
+ * layers as hi/lo f16 planes, three f16 MFMAs per product block; the heads stay fp32 on the fp32
+ * accumulators; every first-layer |weight| < 65504).  ABI 4. */
+int32_t nnv_bitwise_prepack_ex(const nnv_bitwise_desc *net, int32_t precision, nnv_bitwise_handle **out);
 int32_t nnv_bitwise_free(nnv_bitwise_handle *h);
 
 /*

@@ -15,7 +15,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("NNV_LIB") or os.path.join(_PKG_DIR, "libnnviterbi_hip.so")
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 
-NNV_ABI_VERSION = 3
+NNV_ABI_VERSION = 4
 NNV_MAX_LAYERS = 4
 NNV_OK = 0
 NNV_CODE_57 = 0
@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "nnv_mlp_decode_f32_timed", "nnv_mlp_launch_info",
     "nnv_wide_prepack", "nnv_wide_free", "nnv_wide_workspace_bytes", "nnv_wide_decode_f32",
     "nnv_seq2seq_prepack", "nnv_seq2seq_free", "nnv_seq2seq_forward_f32",
-    "nnv_bitwise_prepack", "nnv_bitwise_free", "nnv_bitwise_decode_f32",
+    "nnv_bitwise_prepack", "nnv_bitwise_prepack_ex", "nnv_bitwise_free", "nnv_bitwise_decode_f32",
 )
 
 
@@ -186,6 +186,8 @@ def load_library() -> ctypes.CDLL:
         c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_void_p, c.c_void_p]
     lib.nnv_bitwise_prepack.restype = c.c_int32
     lib.nnv_bitwise_prepack.argtypes = [c.POINTER(BitwiseDesc), c.POINTER(c.c_void_p)]
+    lib.nnv_bitwise_prepack_ex.restype = c.c_int32
+    lib.nnv_bitwise_prepack_ex.argtypes = [c.POINTER(BitwiseDesc), c.c_int32, c.POINTER(c.c_void_p)]
     lib.nnv_bitwise_free.restype = c.c_int32
     lib.nnv_bitwise_free.argtypes = [c.c_void_p]
     lib.nnv_bitwise_decode_f32.restype = c.c_int32

@@ -22,15 +22,22 @@ struct nnv_bitwise_handle {
   int32_t bn;      // 128 (4 positions per column block) or 32 (a single position)
   int32_t mpad;    // 32 * positions rounded up to bn
   int32_t device;
-  float *dev;      // Wt [mpad][kpad] | bias [mpad] | head_w [n_pos][32][2] | head_b [n_pos][2]
+  int32_t precision;  // NNV_PRECISION_F32 | NNV_PRECISION_F16X3
+  float *dev;      // f32:   Wt [mpad][kpad] | bias [mpad] | head_w [n_pos][32][2] | head_b [n_pos][2]
+                   // f16x3: W_hi [mpad][kpad] f16 | W_lo [mpad][kpad] f16 (together the bytes of the fp32 matrix) | bias | ...
   int64_t off_bias, off_hw, off_hb;
 };
 
 extern "C" {
 
 int32_t nnv_bitwise_prepack(const nnv_bitwise_desc *d, nnv_bitwise_handle **out) {
+  return nnv_bitwise_prepack_ex(d, NNV_PRECISION_F32, out);
+}
+
+int32_t nnv_bitwise_prepack_ex(const nnv_bitwise_desc *d, int32_t precision, nnv_bitwise_handle **out) {
   if (!d || !out) return NNV_ERR_INVALID_ARGUMENT;
   *out = nullptr;
+  if (precision != NNV_PRECISION_F32 && precision != NNV_PRECISION_F16X3) return NNV_ERR_INVALID_ARGUMENT;
   if (d->n_input < 2 || d->n_input > 16384 || (d->n_input & 1)) return NNV_ERR_INVALID_ARGUMENT;
   if (d->n_hidden < 1 || d->n_positions < 1) return NNV_ERR_INVALID_ARGUMENT;
   if (d->n_hidden > 32 || d->n_positions > 65536) return NNV_ERR_UNSUPPORTED_SHAPE;
@@ -48,18 +55,31 @@ int32_t nnv_bitwise_prepack(const nnv_bitwise_desc *d, nnv_bitwise_handle **out)
   h->n_pos = d->n_positions;
   h->device = dev;
   h->kpad = (d->n_input + nnv::kDenseBK - 1) / nnv::kDenseBK * nnv::kDenseBK;
-  h->bn = d->n_positions == 1 ? 32 : 128;
+  h->precision = precision;
+  h->bn = (d->n_positions == 1 && precision == NNV_PRECISION_F32) ? 32 : 128;   // the f16x3 GEMM has the 128-column tile only
   h->mpad = (32 * d->n_positions + h->bn - 1) / h->bn * h->bn;
   const int64_t K = d->n_input, H = d->n_hidden, P = d->n_positions;
   h->off_bias = static_cast<int64_t>(h->mpad) * h->kpad;
   h->off_hw = h->off_bias + h->mpad;
   h->off_hb = h->off_hw + P * 64;
   std::vector<float> host(static_cast<size_t>(h->off_hb + 2 * P), 0.f);
+  bool in_range = true;
   for (int64_t pos = 0; pos < P; ++pos) {
     const float *W1 = d->W1_host + pos * K * H;   // [n_input][n_hidden], right-multiply layout
     for (int64_t j = 0; j < H; ++j) {
-      float *row = host.data() + (32 * pos + j) * h->kpad;
-      for (int64_t k = 0; k < K; ++k) row[k] = W1[k * H + j];
+      if (precision == NNV_PRECISION_F16X3) {   // hi plane [mpad][kpad] halves, then the lo plane
+        uint16_t *hi = reinterpret_cast<uint16_t *>(host.data()) + (32 * pos + j) * h->kpad;
+        uint16_t *lo = hi + static_cast<int64_t>(h->mpad) * h->kpad;
+        for (int64_t k = 0; k < K; ++k) {
+          const float v = W1[k * H + j];
+          if (!(v > -65504.f && v < 65504.f)) in_range = false;
+          hi[k] = nnv::f32_to_f16(v);
+          lo[k] = nnv::f32_to_f16(v - nnv::f16_to_f32(hi[k]));
+        }
+      } else {
+        float *row = host.data() + (32 * pos + j) * h->kpad;
+        for (int64_t k = 0; k < K; ++k) row[k] = W1[k * H + j];
+      }
       host[h->off_bias + 32 * pos + j] = d->b1_host[pos * H + j];
       host[h->off_hw + pos * 64 + 2 * j + 0] = d->Wout_host[(pos * H + j) * 2 + 0];
       host[h->off_hw + pos * 64 + 2 * j + 1] = d->Wout_host[(pos * H + j) * 2 + 1];
@@ -68,6 +88,10 @@ int32_t nnv_bitwise_prepack(const nnv_bitwise_desc *d, nnv_bitwise_handle **out)
     host[h->off_hb + 2 * pos + 1] = d->bout_host[2 * pos + 1];
   }
   h->dev = nullptr;
+  if (!in_range) {  // a first-layer weight outside the f16 range: f16x3 refuses, as everywhere else
+    delete h;
+    return NNV_ERR_UNSUPPORTED_SHAPE;
+  }
   if (hipMalloc(reinterpret_cast<void **>(&h->dev), host.size() * sizeof(float)) != hipSuccess) {
     delete h;
     return NNV_ERR_OUT_OF_MEMORY;
@@ -134,6 +158,29 @@ int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, 
   p.head_act = act_dev;
   p.labels = labels_dev;
   p.errors = reinterpret_cast<unsigned long long *>(errors_dev);
+  if (h->precision == NNV_PRECISION_F16X3) {
+    nnv::DenseF16Params q{};
+    q.A_f32 = x_dev;
+    q.a_row_stride = h->n_input;
+    q.n_rows = n_rows;
+    q.K = h->n_input;
+    q.Kpad = h->kpad;
+    q.W_hi = reinterpret_cast<const _Float16 *>(h->dev);
+    q.W_lo = q.W_hi + static_cast<int64_t>(h->mpad) * h->kpad;
+    q.bias = p.bias;
+    q.nblk_m = p.nblk_m;
+    q.nblk_rows = p.nblk_rows;
+    q.act = 2;
+    q.col_group = p.col_group;
+    q.n_pos = p.n_pos;
+    q.head_w = p.head_w;
+    q.head_b = p.head_b;
+    q.bits = p.bits;
+    q.head_act = p.head_act;
+    q.labels = p.labels;
+    q.errors = p.errors;
+    return nnv::bitwise_f16x3_launch(q, static_cast<hipStream_t>(stream));
+  }
   return nnv::bitwise_launch(p, static_cast<hipStream_t>(stream));
 }
 

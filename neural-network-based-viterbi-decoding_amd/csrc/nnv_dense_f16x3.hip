@@ -46,7 +46,10 @@ __device__ __forceinline__ f32x16 mfma16x(u32x4 a, u32x4 b, f32x16 c) {
                                                 0, 0, 0);
 }
 
-template <bool GATHER, int BK>
+// HEAD (the bit-wise decoder BANK in f16x3, round 3): the output columns are P networks' hidden layers, 32 per
+// position, and the epilogue finishes each network in place -- the same epilogue as dense_tanh_kernel<.., HEAD> in
+// nnv_dense.hip, fed from the fp32 accumulators (the hidden values are NOT rounded to f16 on the way to the head).
+template <bool GATHER, int BK, bool HEAD = false>
 __global__ __launch_bounds__(256) void dense_f16x3_kernel(const DenseF16Params p) {
   constexpr int kPlane = BK * 2;            // bytes of one plane segment per row
   constexpr int kRowBytes = 2 * kPlane + 16;
@@ -66,8 +69,22 @@ __global__ __launch_bounds__(256) void dense_f16x3_kernel(const DenseF16Params p
   const int64_t blk = blockIdx.x;
   const int xcd = static_cast<int>(blk & 7);  // same XCD-aware tile map as the fp32 kernel
   const int64_t slot = blk >> 3;
-  const int col_blk = static_cast<int>(slot % p.nblk_m);
-  const int64_t row_blk = (slot / p.nblk_m) * 8 + xcd;
+  int col_blk;
+  int64_t row_blk;
+  if (HEAD && p.col_group > 0) {  // column blocks in L2-sized groups, row blocks fastest inside a group (nnv_dense.hip)
+    const int64_t n_r8 = (p.nblk_rows + 7) / 8;
+    const int64_t per_group = n_r8 * p.col_group;
+    const int groups = (p.nblk_m + p.col_group - 1) / p.col_group;
+    int64_t g = slot / per_group;
+    if (g > groups - 1) g = groups - 1;
+    const int gsz = g == groups - 1 ? p.nblk_m - static_cast<int>(g) * p.col_group : p.col_group;
+    const int64_t rem = slot - g * per_group;
+    col_blk = static_cast<int>(g) * p.col_group + static_cast<int>(rem % gsz);
+    row_blk = (rem / gsz) * 8 + xcd;
+  } else {
+    col_blk = static_cast<int>(slot % p.nblk_m);
+    row_blk = (slot / p.nblk_m) * 8 + xcd;
+  }
   if (row_blk >= p.nblk_rows) return;
   const int64_t row0 = row_blk * kDenseBM;
   const int col0 = col_blk * kDenseBN;
@@ -202,6 +219,68 @@ __global__ __launch_bounds__(256) void dense_f16x3_kernel(const DenseF16Params p
   // epilogue: + bias, activation, split; the block's 128 x 128 tile goes through LDS one plane at
   // a time so that it leaves as whole 256-byte row segments (16 B per lane) instead of 2-byte
   // scattered stores (the accumulator has the neuron on the lane and the rows in registers).
+  if constexpr (HEAD) {
+    // fp32 staging of 64 rows x 128 hidden values at a time (register tile a of both wave row groups), row stride
+    // 136 floats (conflict-free 4-byte writes / 16-byte reads), over the dead operand tiles; then one (row,
+    // position) per thread: relu(h . Wout + bout), first maximum of the two outputs, one byte out.
+    constexpr int kHStride = kDenseBN + 8;
+    static_assert(64 * kHStride * 4 <= (kDenseBM + kDenseBN) * kRowBytes, "head staging must fit the operand tiles");
+    float *const hstage = reinterpret_cast<float *>(lds_all);
+    const int wrow = wave >> 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int lcol = wc + 32 * b + li;
+        const float bias = p.bias[col0 + lcol];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lrow = wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float v = acc[a][b][r] + bias;
+          v = p.act == 2 ? (v > 0.f ? v : 0.f) : tanh_f32x(v);
+          hstage[lrow * kHStride + lcol] = v;
+        }
+      }
+      __syncthreads();
+      const int lrow = tid & 63;
+      const int lpos = __builtin_amdgcn_readfirstlane(tid >> 6);   // a wave holds ONE position
+      const int64_t pos = static_cast<int64_t>(col_blk) * 4 + lpos;
+      const int64_t row = row0 + (lrow >> 5) * 64 + 32 * a + (lrow & 31);
+      if (pos < p.n_pos) {
+        const float *hw = p.head_w + pos * 64;
+        const float *hv = hstage + lrow * kHStride + 32 * lpos;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 h4 = *reinterpret_cast<const f32x4 *>(hv + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0 = __builtin_fmaf(h4[e], hw[2 * (4 * q + e)], s0);
+            s1 = __builtin_fmaf(h4[e], hw[2 * (4 * q + e) + 1], s1);
+          }
+        }
+        float v0 = s0 + p.head_b[2 * pos], v1 = s1 + p.head_b[2 * pos + 1];
+        v0 = v0 > 0.f ? v0 : 0.f;
+        v1 = v1 > 0.f ? v1 : 0.f;
+        const unsigned bit = v1 > v0 ? 1u : 0u;
+        const bool live = row < p.n_rows;
+        if (live) {
+          p.bits[pos * p.n_rows + row] = static_cast<uint8_t>(bit);
+          if (p.head_act) {
+            const f32x2 o = {v0, v1};
+            *reinterpret_cast<f32x2 *>(p.head_act + (pos * p.n_rows + row) * 2) = o;
+          }
+        }
+        if (p.errors) {
+          const bool wrong = live && p.labels[pos * p.n_rows + row] != bit;
+          const unsigned long long m = __ballot(wrong);
+          if (lane == 0 && m) atomicAdd(p.errors + pos, static_cast<unsigned long long>(__popcll(m)));
+        }
+      }
+    }
+    return;
+  }
   constexpr int kOutStride = kDenseBN * 2 + 16;  // bytes per staged row
   static_assert(kDenseBM * kOutStride <= 2 * kDenseBM * kRowBytes, "output staging must fit the operand tiles");
   _Float16 lo_keep[2][2][16];
@@ -291,6 +370,14 @@ nnv_status dense_f16x3_launch(const DenseF16Params &p, bool gather, hipStream_t 
     hipLaunchKernelGGL((dense_f16x3_kernel<false, 64>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
   else
     hipLaunchKernelGGL((dense_f16x3_kernel<false, 32>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+}
+
+nnv_status bitwise_f16x3_launch(const DenseF16Params &p, hipStream_t stream) {
+  const int64_t blocks = (p.nblk_rows + 7) / 8 * 8 * p.nblk_m;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return NNV_ERR_INVALID_ARGUMENT;
+  if (!p.bits || !p.head_w || !p.head_b || (p.errors && !p.labels)) return NNV_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL((dense_f16x3_kernel<true, 32, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
   return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 

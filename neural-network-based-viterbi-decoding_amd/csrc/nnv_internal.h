@@ -264,6 +264,15 @@ struct DenseF16Params {
   int32_t nblk_m;
   int64_t nblk_rows;
   int32_t act;            // 1 tanh, 2 relu
+  // fused per-position head (bitwise_f16x3_launch only; same meaning as in DenseParams)
+  int32_t col_group;
+  int64_t n_pos;
+  const float *head_w;
+  const float *head_b;
+  uint8_t *bits;
+  float *head_act;
+  const uint8_t *labels;
+  unsigned long long *errors;
 };
 struct HeadF16Params {
   const _Float16 *A_hi, *A_lo;
@@ -281,6 +290,7 @@ nnv_status dense_f16x3_launch(const DenseF16Params &p, bool gather, hipStream_t 
 nnv_status head_f16x3_launch(const HeadF16Params &p, hipStream_t stream);
 nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream);
 nnv_status bitwise_launch(const DenseParams &p, hipStream_t stream);
+nnv_status bitwise_f16x3_launch(const DenseF16Params &p, hipStream_t stream);
 nnv_status head_launch(const HeadParams &p, hipStream_t stream);
 
 // nnv_generator.hip

@@ -367,8 +367,11 @@ class BitwiseBank:
     (src/fnn_viterbi_bitwise.py:326-399,503-505).  ``models`` is a sequence of
     ``(W1 [n_input, n_hidden], b1 [n_hidden], Wout [n_hidden, 2], bout [2])``, one per position."""
 
-    def __init__(self, models: Sequence, device=None):
+    def __init__(self, models: Sequence, device=None, precision: Optional[str] = None):
+        """``precision``: "f32" (exact fp32 MFMA GEMM) or "f16x3" (the stacked first layers as hi/lo f16 planes on
+        the 16-bit matrix pipe, fp32 accumulate; the heads stay fp32 on the fp32 accumulators)."""
         _require_cuda()
+        self.precision = _resolve_precision(precision)
         self._lib = _cabi.load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()
                                    if device is None else torch.device(device).index or 0)
@@ -388,8 +391,8 @@ class BitwiseBank:
         desc.Wout_host, desc.bout_host = Wo.ctypes.data, bo.ctypes.data
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _cabi.check(self._lib.nnv_bitwise_prepack(ctypes.byref(desc), ctypes.byref(handle)),
-                        "nnv_bitwise_prepack")
+            _cabi.check(self._lib.nnv_bitwise_prepack_ex(ctypes.byref(desc), _cabi.NNV_PRECISION[self.precision],
+                                                         ctypes.byref(handle)), "nnv_bitwise_prepack_ex")
         self._handle = handle
 
     def close(self):

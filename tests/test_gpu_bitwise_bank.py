@@ -38,15 +38,16 @@ def _check_position(bits, act, x, w, b):
     return int(bad.sum())
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])   # exact fp32 MFMA GEMM | hi/lo f16 planes (round 3), heads fp32
 @pytest.mark.parametrize("block_length,n_pos,n_rows", [(512, 9, 1500), (24, 24, 777), (24, 1, 300),
                                                        (24, 4, 128), (25, 6, 129), (40, 3, 1)])
-def test_bank_matches_oracle_per_position(cuda_device, block_length, n_pos, n_rows):
+def test_bank_matches_oracle_per_position(cuda_device, block_length, n_pos, n_rows, precision):
     cfg = bw.BitwiseDecoderConfig(block_length=block_length, training_size=4, test_size=n_rows, test_snr_index=3)
     np.random.seed(block_length + n_pos)
     info, enc = bw.generate_test_data(cfg)
     models = _models(cfg, n_pos, seed=7)
     x = enc.astype(np.float32)
-    bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models])
+    bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models], precision=precision)
     labels = torch.from_numpy(np.ascontiguousarray(info[:, :n_pos].T.astype(np.uint8))).cuda()
     r = bank.decode(torch.from_numpy(x).cuda(), labels=labels, want_act=True)
     bits, act, errors = r["bits"].cpu().numpy(), r["act"].cpu().numpy(), r["errors"].cpu().numpy()
@@ -88,6 +89,13 @@ def test_bank_argument_validation(cuda_device):
     with pytest.raises(ValueError):
         bank.decode(x, labels=torch.zeros((10, 2), dtype=torch.uint8, device="cuda"))  # [P, N], not [N, P]
     bank.close()
+    big = [(w["h1"].copy(), b["b1"], w["out"], b["out"]) for w, b in models]
+    big[1][0][3, 2] = 70000.0                                          # outside the f16 range: f16x3 refuses, f32 does not
+    with pytest.raises(nnviterbi_amd.NNViterbiError):
+        BitwiseBank(big, precision="f16x3")
+    BitwiseBank(big, precision="f32").close()
+    with pytest.raises(ValueError):
+        BitwiseBank(big, precision="f16")                              # the single-product mode is nnv_mlp_* only
     with pytest.raises(Exception):
         BitwiseBank([(np.zeros((60, 40), np.float32), np.zeros(40, np.float32),       # n_hidden > 32
                       np.zeros((40, 2), np.float32), np.zeros(2, np.float32))])

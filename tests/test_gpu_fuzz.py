@@ -106,8 +106,9 @@ def test_fused_decoder_random_shapes_many_rows(cuda_device, seed, precision):
     net.close()
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("seed", range(8 * SCALE))
-def test_bitwise_bank_random_shapes(cuda_device, seed):
+def test_bitwise_bank_random_shapes(cuda_device, seed, precision):
     """K4b: random input width (even), hidden width <= 32, 1..40 positions, ragged rows."""
     from nnviterbi_amd.decoder import BitwiseBank
     rng = np.random.RandomState(4000 + seed)
@@ -119,7 +120,7 @@ def test_bitwise_bank_random_shapes(cuda_device, seed):
         models.append((Ws[0], bs[0], Ws[1], bs[1]))
     x = np.trunc(rng.randn(n, K) * 1.5).astype(np.float32)
     labels = (rng.rand(P, n) > 0.5).astype(np.uint8)
-    bank = BitwiseBank(models)
+    bank = BitwiseBank(models, precision=precision)
     r = bank.decode(torch.from_numpy(x).cuda(), labels=torch.from_numpy(labels).cuda(), want_act=True)
     bits, act, err = r["bits"].cpu().numpy(), r["act"].cpu().numpy(), r["errors"].cpu().numpy()
     for p_ in range(P):

@@ -68,6 +68,10 @@ for p in (0, P // 2, P - 1):
     refp = O.decode_c(xs, [models[p][0], models[p][2]], [models[p][1], models[p][3]], 1, want_bits=False,
                       activation="relu")
     mismP += int((refp["cls"] != bitsP[p]).sum())
+bank16 = BitwiseBank(models, precision="f16x3")
+msP16, rP16 = timed(lambda: bank16.decode(x), max(2, args.steps // 4))
+flips16 = int((rP16["bits"] != rP["bits"]).sum().item())
+bank16.close()
 # ---- one position through the fused kernel (32-column tile + head in the epilogue) ------------
 bank1 = BitwiseBank(models[:1])
 ms1f, r1f = timed(lambda: bank1.decode(x), args.steps)
@@ -103,6 +107,12 @@ print(json.dumps({
                      "hbm_frac_of_8TBs": bytes_row * n / (msP * 1e-3) / 8.0e12},
         "speedup_vs_one_launch_per_position": ms1 * P / msP,
         "parity_sample": {"rows": m, "positions_checked": 3, "class_mismatches": mismP},
+    },
+    "bank_f16x3": {
+        "what": f"the same {P} positions with the stacked first layers as hi/lo f16 planes (BitwiseBank(precision='f16x3'))",
+        "value": n / (msP16 * 1e-3), "unit": "rows/s (all positions decoded)", "ms_per_step": msP16,
+        "speedup_vs_fp32_bank": msP / msP16, "decided_bits_differing_from_the_fp32_bank": flips16,
+        "decided_bits": n * P,
     },
     "cpu_baseline": {"value": m / dt, "unit": "rows/s (one position)", "cores": O.c_max_threads(), "kind": "port",
                      "sample": f"first {m} rows, oracle/fnn_oracle.c"},
