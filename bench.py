@@ -532,12 +532,19 @@ def main():
             "note": "operands rounded once to f16, one MFMA per product block: OUTSIDE the 1e-5 parity contract "
                     "(tests/test_gpu_f16_mode.py states its own tolerance); BASELINE's bar for it is |dBER| <= 1e-4",
         }
+        # the legs below come after the headline measurement: a failure in one of them must not cost the line
         if world == 1:
-            out["other_baseline_configs"] = other_baseline_configs(dev, max(3, args.steps // 2), net)
+            try:
+                out["other_baseline_configs"] = other_baseline_configs(dev, max(3, args.steps // 2), net)
+            except Exception as e:   # noqa: BLE001  (reported, never silently dropped)
+                out["other_baseline_configs"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
-            base, parity = cpu_baseline(x, labels, Ws, bs, cls)
-            out["cpu_baseline"] = base
-            out["parity_sample"] = parity
+            try:
+                base, parity = cpu_baseline(x, labels, Ws, bs, cls)
+                out["cpu_baseline"] = base
+                out["parity_sample"] = parity
+            except Exception as e:   # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
     nd.barrier(dev)
     if world > 1:
