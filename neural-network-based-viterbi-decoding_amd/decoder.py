@@ -371,7 +371,10 @@ class BitwiseBank:
         """``precision``: "f32" (exact fp32 MFMA GEMM) or "f16x3" (the stacked first layers as hi/lo f16 planes on
         the 16-bit matrix pipe, fp32 accumulate; the heads stay fp32 on the fp32 accumulators)."""
         _require_cuda()
+        explicit = precision is not None
         self.precision = _resolve_precision(precision)
+        if self.precision == "f16x3" and not explicit and len(models) < 2:
+            self.precision = "f32"    # one position is HBM-shaped: the 32-column fp32 tile (0.29 ms) beats the f16x3 GEMM (0.42 ms)
         self._lib = _cabi.load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()
                                    if device is None else torch.device(device).index or 0)

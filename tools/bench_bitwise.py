@@ -75,6 +75,10 @@ bank16.close()
 # ---- one position through the fused kernel (32-column tile + head in the epilogue) ------------
 bank1 = BitwiseBank(models[:1])
 ms1f, r1f = timed(lambda: bank1.decode(x), args.steps)
+bank1h = BitwiseBank(models[:1], precision="f16x3")
+ms1h, r1h = timed(lambda: bank1h.decode(x), args.steps)
+flips1h = int((r1h["bits"] != r1f["bits"]).sum().item())
+bank1h.close()
 ref0 = O.decode_c(xs, [models[0][0], models[0][2]], [models[0][1], models[0][3]], 1, want_bits=False, activation="relu")
 mism1f = int((ref0["cls"] != r1f["bits"][0, :m].cpu().numpy()).sum())
 flop_row = 2 * cfg.n_input * cfg.n_hidden_1 * P + 2 * cfg.n_hidden_1 * 2 * P
@@ -96,6 +100,12 @@ print(json.dumps({
         "roofline": {"bound": "hbm", "achieved": (4 * cfg.n_input + 1) * n / (ms1f * 1e-3) / 1e9, "peak": 8000.0,
                      "unit": "GB/s", "frac": (4 * cfg.n_input + 1) * n / (ms1f * 1e-3) / 8.0e12},
         "parity_sample": {"rows": m, "class_mismatches": mism1f},
+    },
+    "single_fused_f16x3": {
+        "what": "one bit position, f16x3 (128-column tile, 3 of its 4 position slots empty)", "value": n / (ms1h * 1e-3),
+        "unit": "rows/s", "ms_per_step": ms1h, "decided_bits_differing_from_fp32": flips1h,
+        "roofline": {"bound": "hbm", "achieved": (4 * cfg.n_input + 1) * n / (ms1h * 1e-3) / 1e9, "peak": 8000.0,
+                     "unit": "GB/s", "frac": (4 * cfg.n_input + 1) * n / (ms1h * 1e-3) / 8.0e12},
     },
     "bank": {
         "what": f"{P} positions in one fused launch (decoder.BitwiseBank)", "positions": P,
