@@ -94,6 +94,31 @@ int main(void) {
     host_ok = diff == 0 && cnt[2] == (uint64_t)m * B && cnt[3] == (uint64_t)m;
     free(xh); free(lh); free(dev_cls); free(ch);
   }
+  /* ---- the other arithmetic modes (nnv_mlp_prepack_ex) on the same 2 dB rows: f16x3 keeps the 1e-5 parity rules,
+   *      f16 (one rounding to f16 per operand) is the opt-in fast mode outside them ---- */
+  int modes_ok = 1;
+  {
+    int32_t *ref = malloc((size_t)n_rows * sizeof(int32_t)), *got = malloc((size_t)n_rows * sizeof(int32_t));
+    CHECK_HIP(hipMemcpy(ref, cls, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int32_t modes[2] = {NNV_PRECISION_F16X3, NNV_PRECISION_F16};
+    const char *names[2] = {"f16x3", "f16"};
+    for (int k = 0; k < 2; ++k) {
+      nnv_mlp_handle *hm = NULL;
+      CHECK_NNV(nnv_mlp_prepack_ex(&net, modes[k], &hm));
+      CHECK_HIP(hipMemset(counters, 0, 4 * sizeof(uint64_t)));
+      CHECK_NNV(nnv_mlp_decode_f32(hm, x, n_rows, B, labels, cls, NULL, NULL, counters, NULL));
+      CHECK_HIP(hipDeviceSynchronize());
+      CHECK_HIP(hipMemcpy(got, cls, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToHost));
+      CHECK_HIP(hipMemcpy(host, counters, sizeof(host), hipMemcpyDeviceToHost));
+      int64_t diff = 0;
+      for (int64_t i = 0; i < n_rows; ++i) diff += got[i] != ref[i];
+      printf("mode %s: %lld of %lld classes differ from the fp32 mode, BER %.3e\n", names[k], (long long)diff,
+             (long long)n_rows, (double)host[0] / (double)host[2]);
+      modes_ok = modes_ok && diff <= (k == 0 ? 8 : n_rows / 100);   /* f16x3: near-ties only */
+      CHECK_NNV(nnv_mlp_free(hm));
+    }
+    free(ref); free(got);
+  }
   /* ---- the device rule: a handle is refused on any device but the one it was packed for ---- */
   int dev = -1;
   CHECK_HIP(hipGetDevice(&dev));
@@ -129,10 +154,19 @@ int main(void) {
     printf("bit-wise bank: %d positions x %d rows, %d wrong\n", P, NR, bad);
     bank_ok = bad == 0;
     CHECK_NNV(nnv_bitwise_free(bh));
+    CHECK_NNV(nnv_bitwise_prepack_ex(&bd, NNV_PRECISION_F16X3, &bh));   /* the same bank on the 16-bit matrix pipe */
+    CHECK_NNV(nnv_bitwise_decode_f32(bh, xd, NR, bits_d, NULL, NULL, NULL, NULL));
+    CHECK_HIP(hipMemcpy(bits_h, bits_d, P * NR, hipMemcpyDeviceToHost));
+    bad = 0;
+    for (int p = 0; p < P; ++p)
+      for (int r = 0; r < NR; ++r) bad += bits_h[p * NR + r] != (xs[r * K + 12 + 2 * p] > 0.0f);
+    printf("bit-wise bank f16x3: %d wrong\n", bad);
+    bank_ok = bank_ok && bad == 0;
+    CHECK_NNV(nnv_bitwise_free(bh));
     hipFree(xd); hipFree(bits_d);
     free(w1); free(bb1); free(wo); free(bo); free(xs); free(bits_h);
   }
   CHECK_NNV(nnv_mlp_free(h));
   hipFree(x); hipFree(labels); hipFree(cls); hipFree(counters);
-  return (exact && host_ok && rule_ok && bank_ok) ? 0 : 4;
+  return (exact && host_ok && rule_ok && bank_ok && modes_ok) ? 0 : 4;
 }

@@ -40,3 +40,5 @@ def test_c_example_round_trip_is_exact(tmp_path, cuda_device):
     assert 1e-3 < ber < 2e-2          # per-tile ML decision of the (133,171) b = 8 tile code at 2 dB
     assert "host entry: 1000007 rows, 0 differ from the resident decode" in r.stdout
     assert "refused: yes" in r.stdout and "bit-wise bank: 3 positions x 5000 rows, 0 wrong" in r.stdout
+    assert "bit-wise bank f16x3: 0 wrong" in r.stdout          # nnv_bitwise_prepack_ex from C
+    assert "mode f16x3:" in r.stdout and "mode f16:" in r.stdout   # nnv_mlp_prepack_ex, all three arithmetic modes
