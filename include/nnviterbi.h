@@ -55,8 +55,10 @@ typedef enum nnv_precision {
                               ~2^-21 relative error per product, ~3x faster    */
   NNV_PRECISION_F16 = 2    /* nnv_mlp_* only: operands rounded ONCE to f16 (11 bits), one f16 MFMA
                               per product block, fp32 accumulate.  OUTSIDE the 1e-5 parity contract
-                              (outputs within ~2e-3 of float64; class flips and BER delta are reported
-                              by bench.py): the opt-in "fast mode with measured BER delta"            */
+                              (outputs within 1e-2 of float64 = the tested bound, 7.8e-3 observed on
+                              the trained config-3 network; no reference fixture pins this mode; class
+                              flips and BER delta are reported by bench.py): the opt-in "fast mode
+                              with measured BER delta"                                                */
 } nnv_precision;
 
 /* Convolutional codes of the reference's generators. */

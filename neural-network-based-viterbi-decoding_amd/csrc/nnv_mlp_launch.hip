@@ -86,14 +86,24 @@ int decode_kernel_vgprs(const PackedShape &s, int threads, bool lean) {
 }
 
 // Resident or streamed?  The whole network stays in LDS (general / lean variants) iff it fits beside the
-// argmax winner slots of the workgroup size that variant runs at; otherwise the class layer is swept
-// through the LDS ring (stream variant).  The workgroup size is picked first, per variant, so a network
-// that fits at 512 threads is not demoted because it would not fit at 1024.
+// argmax winner slots of the workgroup size pick_threads_impl chooses for the resident variant (1024 threads =
+// 64 KB of slots unless that instantiation spills); otherwise the class layer is swept through the LDS ring
+// (stream variant) at ITS workgroup size.  In between sits a band -- whole network 96..128 KB, e.g.
+// 18->128->64->32->512 (120 KB packed) -- that fits resident beside 512 threads' 32 KB of slots only.  There
+// the network stays RESIDENT at 512 threads (round 3 demoted it to the ring without trying).
+// Measured, round 4, one box, 18->128->64->32->512 over 4 M rows, two runs each (tools/bench_band.py):
+//   resident / 512 threads: fp32 2.001-2.010 ms, f16x3 0.900-0.917 ms
+//   ring / 1024 threads   : fp32 2.038-2.052 ms, f16x3 1.018-1.034 ms      (+2 % / +12 %)
+// -- unlike a 1024-class layer (configs[1]: 0.79 at 512 threads vs 0.85 through the ring at 1024), a class
+// layer this small is cheaper to keep than to sweep in lock step.  NNV_BAND_RING_1024=1 forces the ring
+// (A/B runs and the ring tests of this shape only).
 int decode_configure(PackedShape *s, int lds_limit) {
+  static const bool band_ring_1024 = getenv("NNV_BAND_RING_1024") != nullptr;
   const int64_t whole = (s->hid_floats + s->out_floats + s->bias_floats) * 4 + kLdsTailBytes;
   s->streams = 0;
   const int t = pick_threads_impl(*s);
   if (whole + keep_slot_bytes(t) <= lds_limit) return t;
+  if (!band_ring_1024 && t > 512 && whole + keep_slot_bytes(512) <= lds_limit) return 512;
   s->streams = 1;
   // ring-swept: hidden layers + biases + winner slots + ring must fit; a network with a very large class
   // layer's biases (4096 classes: 16 KB) falls back to 512 threads (half the winner slots)

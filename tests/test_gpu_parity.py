@@ -89,8 +89,9 @@ SHAPES = [
     ([16, 128, 256], 8),             # 1 hidden layer
     ([16, 100, 50, 20, 256], 8),     # hidden widths that are not multiples of 32
     ([24, 128, 64, 32, 4096], 12),   # widest supported input, 4096 classes
-    ([18, 128, 64, 32, 512], 9),     # 120 KB packed: fits the LDS alone, not beside 1024 threads' winner slots
-                                     # (the resident / ring-swept decision is taken with the workgroup size)
+    ([18, 128, 64, 32, 512], 9),     # 120 KB packed: fits the LDS beside 512 threads' winner slots, not beside 1024's
+                                     # (resident at 512 threads there, measured faster than the ring at 1024)
+    ([22, 128, 64, 32, 2048], 11),   # 3 hidden layers + a 256 KB class layer: the ring with 32-input class tiles
 ]
 
 
@@ -527,7 +528,7 @@ def test_baseline_configs_0_and_1_at_full_size(cuda_device, precision, code, b, 
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("dims,b", [([20, 128, 64, 1024], 10), ([20, 128, 64, 32, 1024], 10), ([18, 128, 64, 32, 512], 9)])
+@pytest.mark.parametrize("dims,b", [([20, 128, 64, 1024], 10), ([20, 128, 64, 32, 1024], 10), ([22, 128, 64, 32, 2048], 11)])
 def test_ring_swept_class_layer_matches_the_oracle_over_many_rounds(cuda_device, dims, b, precision):
     """Stream variant, dense random weights, 300,077 rows = 9,378 row tiles: every workgroup runs 2-3 rounds with all
     16 waves busy and a ragged last round (waves without a tile only keep the ring going).  EVERY row against the C
@@ -540,6 +541,31 @@ def test_ring_swept_class_layer_matches_the_oracle_over_many_rounds(cuda_device,
     labels = rng.randint(0, dims[-1], n).astype(np.int32)
     net = PackedMLP(Ws, bs, precision=precision)
     assert net.launch_info(n)["out_layer_in_lds"] == 0
+    r = net.decode(torch.from_numpy(x).cuda(), labels=torch.from_numpy(labels).cuda(), tile_bits=b)
+    cls = r["cls32"].cpu().numpy()
+    ref = O.decode_c(x, Ws, bs, b, labels=labels, want_bits=False)
+    diff = np.flatnonzero(cls != ref["cls"])
+    assert len(diff) <= 10
+    if len(diff):
+        _assert_parity(cls[diff], None, x[diff], Ws, bs, b)
+    assert np.array_equal(r["counters"].cpu().numpy(), O.error_counters(cls, labels, b))
+    net.close()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_band_network_stays_resident_at_512_threads(cuda_device, precision):
+    """a network that fits the LDS beside 512 threads' winner slots but not beside 1024's (18->128->64->32->512,
+    120 KB packed) is kept RESIDENT at 512 threads -- measured faster than the ring at 1024 -- and every
+    row over several rounds of the persistent workgroups agrees with the C oracle under the near-tie rule."""
+    dims, b = [18, 128, 64, 32, 512], 9
+    Ws, bs = _net(dims, seed=50)
+    n = 300_077
+    rng = np.random.RandomState(13)
+    x = (rng.randn(n, dims[0]) * 1.1).astype(np.float32)
+    labels = rng.randint(0, dims[-1], n).astype(np.int32)
+    net = PackedMLP(Ws, bs, precision=precision)
+    info = net.launch_info(n)
+    assert info["out_layer_in_lds"] == 1 and info["threads"] == 512 and info["lds_bytes"] <= 160 * 1024
     r = net.decode(torch.from_numpy(x).cuda(), labels=torch.from_numpy(labels).cuda(), tile_bits=b)
     cls = r["cls32"].cpu().numpy()
     ref = O.decode_c(x, Ws, bs, b, labels=labels, want_bits=False)

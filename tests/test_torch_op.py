@@ -135,6 +135,61 @@ def test_pack_cache_is_bounded(fake_pack):
     assert all(n.closed for n in nets[:4]) and not any(n.closed for n in nets[4:])
 
 
+@pytest.mark.parametrize("alias", ["same", "detach", "data", "view"])
+@pytest.mark.parametrize("write", ["param", "param_data", "alias"])
+def test_pack_cache_sees_every_in_place_write(fake_pack, alias, write):
+    """``p.data`` carries a fresh version counter that is always 0 and a write through
+    ``p.data`` does not bump ``p``'s own, so no counter sees ``[p.data for p in params]`` after an optimizer
+    step.  Whatever alias is passed and whatever alias is written through, the next call must re-pack
+    with the new values -- and an untouched network must keep hitting."""
+    params = [torch.nn.Parameter(torch.full((4, 8), 1.0)), torch.nn.Parameter(torch.full((8, 4), 1.0))]
+    biases = [torch.nn.Parameter(torch.zeros(8)), torch.nn.Parameter(torch.zeros(4))]
+
+    def passed(ts):
+        return {"same": lambda t: t, "detach": lambda t: t.detach(), "data": lambda t: t.data,
+                "view": lambda t: t.detach().view(t.shape)}[alias]
+
+    def call():
+        return decoder._cached_pack([passed(params)(t) for t in params], [passed(biases)(t) for t in biases], "cpu")
+
+    n1 = call()
+    assert call() is n1 and len(fake_pack.made) == 1 and n1.tag == 1.0          # untouched: a hit
+    with torch.no_grad():
+        if write == "param":
+            params[0].add_(1.0)                   # what optimizer.step() does
+        elif write == "param_data":
+            params[0].data.add_(1.0)              # bumps no counter the caller can see
+        else:
+            passed(params)(params[0]).add_(1.0)   # through an alias of the kind that is passed
+    n2 = call()
+    assert n2 is not n1 and n2.tag == 2.0 and n1.closed, "decoded with the network packed before the write"
+    assert call() is n2 and len(fake_pack.made) == 2
+    with torch.no_grad():
+        biases[1].data[3] = -0.0                   # a bias, one element, value-equal but another bit pattern
+    assert call() is not n2
+
+
+def test_default_precision_never_resolves_to_f16(monkeypatch):
+    """'f16 is explicit opt-in only' must hold for the environment too."""
+    assert decoder._resolve_precision("f16", allow_f16=True) == "f16"          # explicit argument: allowed
+    with pytest.raises(ValueError):
+        decoder._resolve_precision("f16")
+    monkeypatch.setenv("NNV_PRECISION", "f16")
+    with pytest.warns(RuntimeWarning):
+        assert decoder._default_precision_from_env() == "f32"
+    monkeypatch.setenv("NNV_PRECISION", "f16x3")
+    assert decoder._default_precision_from_env() == "f16x3"
+    monkeypatch.setenv("NNV_PRECISION", "bogus")
+    with pytest.warns(RuntimeWarning):
+        assert decoder._default_precision_from_env() == "f32"
+    # even a default forced past the setter cannot reach the single-product mode
+    monkeypatch.setattr(decoder, "_DEFAULT_PRECISION", ["f16"])
+    with pytest.raises(ValueError):
+        decoder._resolve_precision(None, allow_f16=True)
+    with pytest.raises(ValueError):
+        decoder.set_default_precision("f16")
+
+
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,depth,b", CASES)
@@ -180,3 +235,41 @@ def test_reloaded_checkpoint_is_not_decoded_with_the_old_network(cuda_device):
     assert len(decoder._PACK_CACHE) == 1        # the first checkpoint's entry went when the second was packed;
     decoder._sweep_dead_entries()               # the second one's goes at the next call (never from the GC)
     assert len(decoder._PACK_CACHE) == 0
+
+
+@pytest.mark.gpu
+def test_optimizer_step_behind_the_data_idiom_is_decoded_with_the_new_weights(cuda_device):
+    """ADVICE r3 (high) on real device tensors: pass ``[p.data for p in params]``, update the parameters in
+    place (what ``optimizer.step()`` does), call again -- no version counter moves, the bytes do."""
+    from nnviterbi_amd import fnn_viterbi as fv
+    decoder.clear_pack_cache()
+    cfg = fv.DecoderConfig(block_length=8)
+    w, b = fv.initialize_weights(cfg, rng=np.random.RandomState(21))
+    Ws, bs = fv.weights_as_lists(w, b)
+    params = [torch.nn.Parameter(t) for t in _t(Ws, "cuda") + _t(bs, "cuda")]
+    x = torch.randn(8192, 16, device="cuda", generator=torch.Generator("cuda").manual_seed(5))
+
+    def op():
+        ts = [p.data for p in params]
+        return torch.ops.nnviterbi.mlp_decode(x, ts[:4], ts[4:], 8)[0].cpu()
+
+    def fresh():
+        net = decoder.PackedMLP([p.detach() for p in params[:4]], [p.detach() for p in params[4:]])
+        try:
+            return net.decode(x, want_cls32=False, want_cls64=True)["cls64"].cpu()
+        finally:
+            net.close()
+
+    c1 = op()
+    assert torch.equal(c1, fresh()) and torch.equal(op(), c1) and len(decoder._PACK_CACHE) == 1
+    opt = torch.optim.SGD(params, lr=1.0)
+    for p in params:
+        p.grad = torch.randn(p.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(p.numel()))
+    opt.step()
+    c2 = op()
+    assert torch.equal(c2, fresh()), "the op decoded with the network packed before optimizer.step()"
+    assert (c2 != c1).float().mean() > 0.2
+    with torch.no_grad():
+        params[0].data.mul_(-1.0)                 # a write no counter records at all
+    assert torch.equal(op(), fresh())
+    decoder.clear_pack_cache()
