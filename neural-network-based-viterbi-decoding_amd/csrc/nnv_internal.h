@@ -293,6 +293,33 @@ nnv_status bitwise_launch(const DenseParams &p, hipStream_t stream);
 nnv_status bitwise_f16x3_launch(const DenseF16Params &p, hipStream_t stream);
 nnv_status head_launch(const HeadParams &p, hipStream_t stream);
 
+// nnv_wide_fused.hip (K6): the whole wide network in one persistent launch, activations resident in LDS.
+// Eligible: fp32, every hidden width <= 512 (16 waves x one 32-neuron tile), row length <= 512, <= 32 classes.
+constexpr int kFusedRows = 64, kFusedThreads = 1024, kFusedMaxHidden = 7, kFusedMaxWidth = 512;
+struct WideFusedParams {
+  const float *x;          // row i starts at x + i * row_stride
+  int64_t row_stride;
+  int64_t n_rows;
+  int64_t n_blocks;        // ceil(n_rows / 64)
+  int32_t x16;             // every row start 16-byte aligned
+  int32_t K0;              // true row length
+  int32_t n_hidden;        // layers on the matrix cores
+  int32_t groups[kFusedMaxHidden];     // ceil(K_l / 8): fragment groups (8 inputs) per neuron tile
+  int32_t tiles[kFusedMaxHidden];      // ceil(M_l / 32): neuron tiles = active waves
+  const float *w[kFusedMaxHidden];     // [tile][group][lane 64][4]: W[8g + 4 (lane >> 5) + e][32 tile + (lane & 31)]
+  const float *bias[kFusedMaxHidden];  // [32 tiles_l], zero padded
+  int32_t act_quads;       // LDS activation buffer, in k-quads of 64 rows x 16 bytes
+  int32_t head_quads;      // k-quads the class layer reads (8 tiles of the last hidden layer)
+  int32_t n_classes;       // <= 32
+  const float *head_w;     // [n_classes][4 head_quads], zero padded
+  const float *head_b;     // [n_classes]
+  int32_t *cls32;          // nullable [n_rows]
+  int64_t *cls64;          // nullable [n_rows]
+  float *act;              // nullable [n_rows][n_classes]
+};
+int64_t wide_fused_lds_bytes(const WideFusedParams &p);
+nnv_status wide_fused_launch(const WideFusedParams &p, int act, int num_cus, int device, hipStream_t stream);
+
 // nnv_generator.hip
 nnv_status generate_launch(int32_t code, int32_t tile_bits, int64_t n_rows,
                            int64_t first_row, int64_t rows_per_block,

@@ -1,4 +1,5 @@
 // C ABI of the layer-at-a-time path (nnv_wide_*): packing, chunking, launches.
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -20,6 +21,11 @@ struct nnv_wide_handle {
   int64_t w_off[NNV_WIDE_MAX_LAYERS], b_off[NNV_WIDE_MAX_LAYERS];
   int32_t max_mpad;
   int32_t device;                     // the HIP device the network was packed for
+  // K6 (nnv_wide_fused.hip): the whole chain in one persistent launch when the shape allows it
+  int32_t fused;                      // 1: fused_dev holds the fragment-order packing
+  int32_t num_cus;
+  float *fused_dev;
+  nnv::WideFusedParams fp;            // static part (pointers into fused_dev, shapes); per-call fields filled at launch
 };
 
 namespace {
@@ -59,6 +65,80 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float *A, int64_t
     if (cls32) cls32[row] = bidx;
     if (cls64) cls64[row] = bidx;
   }
+}
+
+// K6 eligibility + packing.  Hidden layer l: neuron tile t, fragment group g, lane, element e holds
+// W[8g + 4 (lane >> 5) + e][32 t + (lane & 31)] (zero outside the matrix): one wave-load = one contiguous 1 KB,
+// the A operand of four consecutive v_mfma_f32_32x32x2_f32.  Not eligible (fused stays 0, the layer-at-a-time
+// path runs): f16x3, a class layer wider than 32, a hidden width or row length above 512, more than 7 hidden layers.
+nnv_status pack_fused(const nnv_wide_desc *net, nnv_wide_handle *h) {
+  h->fused = 0;
+  h->fused_dev = nullptr;
+  const int nh = net->depth - 1;
+  if (h->f16x3 || !h->head || nh < 1 || nh > nnv::kFusedMaxHidden) return NNV_OK;
+  if (net->dims[0] > nnv::kFusedMaxWidth) return NNV_OK;
+  for (int l = 1; l <= nh; ++l)
+    if (net->dims[l] > nnv::kFusedMaxWidth) return NNV_OK;
+  nnv::WideFusedParams &fp = h->fp;
+  memset(&fp, 0, sizeof(fp));
+  fp.n_hidden = nh;
+  fp.K0 = net->dims[0];
+  int64_t w_off[nnv::kFusedMaxHidden], b_off[nnv::kFusedMaxHidden], total = 0;
+  int act_quads = 0;
+  for (int l = 0; l < nh; ++l) {
+    fp.groups[l] = (net->dims[l] + 7) / 8;
+    fp.tiles[l] = (net->dims[l + 1] + 31) / 32;
+    if (2 * fp.groups[l] > act_quads) act_quads = 2 * fp.groups[l];   // what the layer reads
+    if (8 * fp.tiles[l] > act_quads) act_quads = 8 * fp.tiles[l];     // what it writes
+    w_off[l] = total;
+    total += static_cast<int64_t>(fp.tiles[l]) * fp.groups[l] * 256;
+    b_off[l] = total;
+    total += 32LL * fp.tiles[l];
+  }
+  fp.act_quads = act_quads;
+  fp.head_quads = 8 * fp.tiles[nh - 1];
+  fp.n_classes = net->dims[net->depth];
+  const int64_t hw_off = total;
+  total += static_cast<int64_t>(fp.n_classes) * fp.head_quads * 4;
+  const int64_t hb_off = total;
+  total += round_up(fp.n_classes, 4);
+  if (nnv::wide_fused_lds_bytes(fp) > 160 * 1024) return NNV_OK;
+  std::vector<float> host(static_cast<size_t>(total), 0.f);
+  for (int l = 0; l < nh; ++l) {
+    const int K = net->dims[l], M = net->dims[l + 1];
+    for (int t = 0; t < fp.tiles[l]; ++t)
+      for (int g = 0; g < fp.groups[l]; ++g) {
+        float *grp = host.data() + w_off[l] + (static_cast<int64_t>(t) * fp.groups[l] + g) * 256;
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 4; ++e) {
+            const int k = 8 * g + 4 * (lane >> 5) + e, m = 32 * t + (lane & 31);
+            if (k < K && m < M) grp[lane * 4 + e] = net->W_host[l][static_cast<size_t>(k) * M + m];
+          }
+      }
+    for (int m = 0; m < M; ++m) host[b_off[l] + m] = net->b_host[l][m];
+  }
+  {
+    const int K = net->dims[nh], C = fp.n_classes;
+    for (int c = 0; c < C; ++c)
+      for (int k = 0; k < K; ++k)
+        host[hw_off + static_cast<int64_t>(c) * fp.head_quads * 4 + k] = net->W_host[nh][static_cast<size_t>(k) * C + c];
+    for (int c = 0; c < C; ++c) host[hb_off + c] = net->b_host[nh][c];
+  }
+  if (hipMalloc(reinterpret_cast<void **>(&h->fused_dev), host.size() * sizeof(float)) != hipSuccess)
+    return NNV_ERR_OUT_OF_MEMORY;
+  if (hipMemcpy(h->fused_dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(h->fused_dev);
+    h->fused_dev = nullptr;
+    return NNV_ERR_HIP;
+  }
+  for (int l = 0; l < nh; ++l) {
+    fp.w[l] = h->fused_dev + w_off[l];
+    fp.bias[l] = h->fused_dev + b_off[l];
+  }
+  fp.head_w = h->fused_dev + hw_off;
+  fp.head_b = h->fused_dev + hb_off;
+  h->fused = 1;
+  return NNV_OK;
 }
 
 }  // namespace
@@ -145,6 +225,13 @@ int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out) {
     delete h;
     return NNV_ERR_HIP;
   }
+  h->num_cus = prop.multiProcessorCount;
+  const nnv_status fs = pack_fused(net, h);
+  if (fs != NNV_OK) {
+    (void)hipFree(h->dev);
+    delete h;
+    return fs;
+  }
   *out = h;
   return NNV_OK;
 }
@@ -152,8 +239,9 @@ int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out) {
 int32_t nnv_wide_free(nnv_wide_handle *h) {
   if (!h) return NNV_OK;
   const hipError_t e = hipFree(h->dev);
+  const hipError_t e2 = h->fused_dev ? hipFree(h->fused_dev) : hipSuccess;
   delete h;
-  return e == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+  return (e == hipSuccess && e2 == hipSuccess) ? NNV_OK : NNV_ERR_HIP;
 }
 
 int64_t nnv_wide_workspace_bytes(const nnv_wide_handle *h, int64_t chunk_rows) {
@@ -177,6 +265,23 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev, int64_
   int64_t chunk = workspace_bytes / per_row / 128 * 128;
   if (chunk < 128) return NNV_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // K6: one persistent launch for the whole chain (no workspace traffic).  NNV_WIDE_FUSED=0 keeps the
+  // layer-at-a-time path (A/B runs, and the tests that hold the two paths against each other).
+  if (h->fused) {
+    const char *e = getenv("NNV_WIDE_FUSED");
+    if (!(e && e[0] == '0')) {
+      nnv::WideFusedParams fp = h->fp;
+      fp.x = x_dev;
+      fp.row_stride = row_stride;
+      fp.n_rows = n_rows;
+      fp.n_blocks = (n_rows + nnv::kFusedRows - 1) / nnv::kFusedRows;
+      fp.x16 = (row_stride % 4 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 16 == 0) ? 1 : 0;
+      fp.cls32 = cls32_dev;
+      fp.cls64 = cls64_dev;
+      fp.act = act_dev;
+      return nnv::wide_fused_launch(fp, h->act, h->num_cus, h->device, s);
+    }
+  }
   float *buf[2] = {static_cast<float *>(workspace_dev),
                    static_cast<float *>(workspace_dev) + chunk * h->max_mpad};
   const int last = h->depth - 1;

@@ -238,3 +238,115 @@ def test_default_precision_switch_reaches_the_reference_shaped_modules(cuda_devi
     assert decoder.PackedMLP(*fv.weights_as_lists(w, b)).precision == "f32"
     with pytest.raises(ValueError):
         decoder.set_default_precision("bf16")
+
+
+# ------------------------------------------------------------------ K6: the whole chain in one launch
+def _both_paths(monkeypatch, fn):
+    """fn() through the fused launch (default) and through the layer-at-a-time path (NNV_WIDE_FUSED=0,
+    read per call)."""
+    monkeypatch.delenv("NNV_WIDE_FUSED", raising=False)
+    fused = fn()
+    monkeypatch.setenv("NNV_WIDE_FUSED", "0")
+    layered = fn()
+    monkeypatch.delenv("NNV_WIDE_FUSED", raising=False)
+    return fused, layered
+
+
+FUSED_SHAPES = [
+    ([200, 500, 500, 500, 500, 2], "tanh"),    # the reference's sliding-window network
+    ([14, 300, 70, 5], "tanh"),                # row length not a multiple of 8, widths not multiples of 32, 5 classes
+    ([20, 64, 2], "tanh"),                     # one hidden layer, 2 of 16 waves active
+    ([30, 129, 33, 32], "tanh"),               # 33 -> two neuron tiles with one live neuron in the second; 32 classes
+    ([512, 512, 512, 3], "tanh"),              # the widest eligible row and layers (128 KB of activations)
+    ([10, 40, 40, 40, 40, 40, 40, 40, 7], "tanh"),  # 7 hidden layers (the most), odd class count (row strides are even)
+    ([66, 30, 2], "relu"),                     # a small bit-wise style network: ReLU on every layer, logits included
+    ([200, 500, 500, 2], "relu"),
+]
+
+
+@pytest.mark.parametrize("dims,activation", FUSED_SHAPES)
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4099])
+def test_fused_chain_matches_the_oracle_and_the_layered_path(cuda_device, monkeypatch, dims, activation, n):
+    """K6 (nnv_wide_fused.hip): the hidden activations never leave the CU.  Same contract as the layer-at-a-time
+    path -- outputs within 1e-5 of float64, classes differ only on float64 near-ties -- and the two HIP paths agree
+    with each other to the last bits of the class layer's different summation order (checked: 2e-6)."""
+    Ws, bs = _net(dims, 11 + len(dims))
+    net = WideMLP(Ws, bs, activation=activation)
+    x = (np.random.RandomState(n).randn(n, dims[0]) * 0.9).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    fused, layered = _both_paths(monkeypatch, lambda: net.decode(xd, want_act=True, want_cls64=True))
+    act = fused["act"].cpu().numpy()
+    cls = fused["cls32"].cpu().numpy()
+    c64, _, o64 = O.decode(x, Ws, bs, 1, np.float64, activation=activation)
+    # tanh outputs are bounded: absolute 1e-5.  ReLU outputs are not: the layer-at-a-time tests' relative form
+    tol = TOL if activation == "tanh" else 2e-5 * max(1.0, np.abs(o64).max())
+    assert np.abs(act - o64).max() < tol
+    bad = cls != c64
+    assert not bad.any() or O.top2_margin(o64)[bad].max() < 10 * tol
+    assert np.array_equal(fused["cls64"].cpu().numpy(), cls.astype(np.int64))
+    assert np.abs(act - layered["act"].cpu().numpy()).max() < 0.2 * tol
+    differ = cls != layered["cls32"].cpu().numpy()
+    assert not differ.any() or O.top2_margin(o64)[differ].max() < 10 * tol
+    net.close()
+
+
+def test_fused_chain_on_a_stream_with_every_alignment(cuda_device, monkeypatch):
+    """Windows of a stream (stride 2: 8-byte aligned rows), the same rows as a matrix (16-byte aligned when the row
+    length allows), a stream that does not start on a 16-byte boundary, and a tail block of 1 row."""
+    dims = [200, 500, 500, 500, 500, 2]
+    Ws, bs = _net(dims, 3)
+    net = WideMLP(Ws, bs)
+    n = 64 * 5 + 1
+    s = _stream(n + 1, 200, 17)
+    sd = torch.from_numpy(s).cuda()
+    x = np.ascontiguousarray(np.lib.stride_tricks.sliding_window_view(s, 200)[::2])
+    for first in (0, 1):                                    # window `first` starts 8 * first bytes into the allocation
+        view = sd[2 * first:]
+        fused, layered = _both_paths(monkeypatch, lambda: net.decode_stream(view, n, want_act=True))
+        rows = x[first:first + n]
+        _check(fused["cls32"].cpu().numpy(), fused["act"].cpu().numpy(), rows, Ws, bs)
+        assert np.abs(fused["act"].cpu().numpy() - layered["act"].cpu().numpy()).max() < 2e-6
+        mat = net.decode(torch.from_numpy(rows.copy()).cuda(), want_act=True)
+        assert torch.equal(mat["cls32"], fused["cls32"]) and torch.equal(mat["act"], fused["act"])
+    net.close()
+
+
+def test_fused_chain_is_deterministic_and_row_independent(cuda_device):
+    """One launch twice: identical bits.  A row decoded alone, in the middle of other rows and in another 64-row
+    block: identical outputs (rows are columns of the MFMA's B operand; nothing crosses them)."""
+    dims = [200, 500, 500, 500, 500, 2]
+    Ws, bs = _net(dims, 5)
+    net = WideMLP(Ws, bs)
+    rng = np.random.RandomState(8)
+    x = rng.randn(1000, 200).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    a = net.decode(xd, want_act=True)
+    b = net.decode(xd, want_act=True)
+    assert torch.equal(a["act"], b["act"]) and torch.equal(a["cls32"], b["cls32"])
+    perm = rng.permutation(1000)
+    c = net.decode(xd[torch.from_numpy(perm).cuda()].contiguous(), want_act=True)
+    assert torch.equal(c["act"], a["act"][torch.from_numpy(perm).cuda()])
+    one = net.decode(xd[417:418].contiguous(), want_act=True)
+    assert torch.equal(one["act"][0], a["act"][417])
+    x2 = x.copy()
+    x2[5] = np.nan                                            # a non-finite row stays inside its row
+    d = net.decode(torch.from_numpy(x2).cuda(), want_act=True)
+    keep = np.arange(1000) != 5
+    assert torch.equal(d["act"][torch.from_numpy(keep).cuda()], a["act"][torch.from_numpy(keep).cuda()])
+    net.close()
+
+
+def test_shapes_outside_the_fused_kernel_take_the_layered_path(cuda_device, monkeypatch):
+    """Hidden width above 512, row length above 512, a class layer wider than 32 and the f16x3 mode are not eligible:
+    the layer-at-a-time path decodes them, with or without the switch."""
+    for dims, kw in (([100, 600, 2], {}), ([1036, 30, 2], {"activation": "relu"}), ([16, 256, 128, 64, 256], {}),
+                     ([200, 500, 500, 2], {"precision": "f16x3"})):
+        Ws, bs = _net(dims, 2)
+        net = WideMLP(Ws, bs, **kw)
+        x = np.random.RandomState(3).randn(300, dims[0]).astype(np.float32)
+        xd = torch.from_numpy(x).cuda()
+        a, b = _both_paths(monkeypatch, lambda: net.decode(xd, want_act=True))
+        assert torch.equal(a["act"], b["act"]) and torch.equal(a["cls32"], b["cls32"])
+        c64, _, o64 = O.decode(x, Ws, bs, 1, np.float64, activation=kw.get("activation", "tanh"))
+        assert np.abs(a["act"].cpu().numpy() - o64).max() < 2e-5 * max(1.0, np.abs(o64).max())
+        net.close()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Secondary benchmark (NOT the headline; bench.py is): the reference's sliding-window decoder
-forward (src/fnn_viterbi_seq_predict.py: 200 -> 500 x4 -> 2, window i = stream[2i : 2i+200]) through
-the layer-at-a-time HIP path, with the oracle's C restatement timed beside it on a bounded sample.
+forward (src/fnn_viterbi_seq_predict.py: 200 -> 500 x4 -> 2, window i = stream[2i : 2i+200]): the whole chain
+in one persistent launch (K6, the default), the layer-at-a-time path beside it (K4, NNV_WIDE_FUSED=0) and its f16x3
+mode, with the oracle's C restatement timed on a bounded sample.
 Prints one JSON line.  Usage: python tools/bench_seq_predict.py [--windows 1000000] [--steps 10]"""
 import argparse, json, os, sys, time
 import numpy as np, torch
@@ -32,6 +33,17 @@ for _ in range(args.steps):
     r = net.decode_stream(stream, n)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / args.steps
+os.environ["NNV_WIDE_FUSED"] = "0"          # read per call by nnv_wide_decode_f32: the layer-at-a-time path
+for _ in range(2):
+    rl = net.decode_stream(stream, n)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(args.steps):
+    rl = net.decode_stream(stream, n)
+e1.record(); torch.cuda.synchronize()
+ms_layered = e0.elapsed_time(e1) / args.steps
+layered_diff = int((rl["cls32"] != r["cls32"]).sum().item())
+del os.environ["NNV_WIDE_FUSED"]
 fast = WideMLP(Ws, bs, precision="f16x3")
 for _ in range(2):
     rf = fast.decode_stream(stream, n)
@@ -57,6 +69,10 @@ print(json.dumps({
     "cpu_baseline": {"value": m / dt, "unit": "bits/s", "cores": threads, "kind": "port",
                      "sample": f"first {m} windows, oracle/fnn_oracle.c"},
     "parity_sample": {"windows": m, "class_mismatches": mism},
+    "kernel": "K6 wide_fused_kernel (whole chain in one launch, activations in LDS)",
+    "layer_at_a_time": {"kernel": "K4 dense_tanh_kernel x4 + head", "value": n / (ms_layered * 1e-3), "unit": "bits/s",
+                        "ms_per_step": ms_layered, "frac": flop * n / (ms_layered * 1e-3) / 1e12 / 157.3,
+                        "classes_differing_from_fused": layered_diff},
     "fast_mode": {"dtype": "f16x3", "value": n / (ms_fast * 1e-3), "unit": "bits/s", "ms_per_step": ms_fast,
                   "classes_differing_from_f32": fast_diff},
 }))

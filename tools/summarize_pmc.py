@@ -16,7 +16,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--secondary":
         with open(path, newline="") as f:
             for r in csv.DictReader(f):
                 name = r["Kernel_Name"]
-                if not any(k in name for k in ("dense_tanh_kernel", "dense_f16x3_kernel", "head_argmax", "seq2seq_kernel")):
+                if not any(k in name for k in ("dense_tanh_kernel", "dense_f16x3_kernel", "head_argmax", "seq2seq_kernel", "wide_fused_kernel")):
                     continue
                 if int(r["Grid_Size"]) < 256 * 1024:     # skip the warm-up / tail launches over tiny chunks
                     continue
