@@ -217,6 +217,51 @@ def other_baseline_configs(dev, steps: int, net_headline):
     return out
 
 
+def next_row_paths(dev, steps: int):
+    """SURVEY.md section 8(f) rank 2, measured in the same run (never `value`): the reference's sliding-window decoder
+    forward (src/fnn_viterbi_seq_predict.py:293-336,343-414: window i = stream[2i : 2i+200], 200-500-500-500-500-2,
+    tanh everywhere, argmax = the bit) over its default 1,000,000-window test stream, seeded random weights.
+    K6 = the whole chain in ONE persistent launch (activations resident in LDS, csrc/nnv_wide_fused.hip); the
+    layer-at-a-time path K4 beside it (NNV_WIDE_FUSED=0, read per call by the C ABI)."""
+    from nnviterbi_amd import fnn_viterbi_seq_predict as sq
+    from nnviterbi_amd.decoder import WideMLP
+    cfg = sq.SequentialDecoderConfig()
+    w, b = sq.initialize_weights(cfg, rng=np.random.RandomState(7))
+    Wl, bl = sq.weights_as_lists(w, b)
+    dims = sq.layer_dims(cfg)
+    n = 1_000_000
+    g = torch.Generator(device=dev).manual_seed(3)
+    stream = torch.trunc(torch.sign(torch.randn(2 * n + 400, device=dev, generator=g))
+                         + 0.8 * torch.randn(2 * n + 400, device=dev, generator=g))   # int-valued soft bits (SURVEY F12)
+    net = WideMLP(Wl, bl, device=dev)
+    flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    res = {}
+    for name, env in (("fused_one_launch_K6", None), ("layer_at_a_time_K4", "0")):
+        if env is None:
+            os.environ.pop("NNV_WIDE_FUSED", None)
+        else:
+            os.environ["NNV_WIDE_FUSED"] = env
+        try:
+            r = net.decode_stream(stream, n)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(steps):
+                r = net.decode_stream(stream, n)
+            e1.record()
+            torch.cuda.synchronize(dev)
+        finally:
+            os.environ.pop("NNV_WIDE_FUSED", None)
+        ms = e0.elapsed_time(e1) / steps
+        res[name] = {"value": n / (ms * 1e-3), "unit": "decoded bits/s", "ms_per_step": ms,
+                     "roofline_frac_of_fp32_mfma_peak": flop * n / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f32"],
+                     "ones_decoded": int(r["cls32"].sum().item())}
+    net.close()
+    res["classes_differing_between_the_two_paths"] = None if len({v["ones_decoded"] for v in res.values()}) == 1 else "see ones_decoded"
+    return {"sliding_window": {"workload": f"{n} windows of 200 over one received stream, {'-'.join(str(d) for d in dims)} tanh, "
+                                           f"{flop} FLOP per decoded bit, exact fp32, untrained weights", **res}}
+
+
 def _free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -538,6 +583,11 @@ def main():
                 out["other_baseline_configs"] = other_baseline_configs(dev, max(3, args.steps // 2), net)
             except Exception as e:   # noqa: BLE001  (reported, never silently dropped)
                 out["other_baseline_configs"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1:
+            try:
+                out["next_rows"] = next_row_paths(dev, max(3, args.steps // 4))
+            except Exception as e:   # noqa: BLE001
+                out["next_rows"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 base, parity = cpu_baseline(x, labels, Ws, bs, cls)

@@ -300,7 +300,7 @@ struct WideFusedParams {
   const float *x;          // row i starts at x + i * row_stride
   int64_t row_stride;
   int64_t n_rows;
-  int64_t n_blocks;        // ceil(n_rows / 64)
+  int64_t n_units;         // ceil(n_rows / 32): 32-row work units
   int32_t x16;             // every row start 16-byte aligned
   int32_t K0;              // true row length
   int32_t n_hidden;        // layers on the matrix cores

@@ -274,7 +274,7 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev, int64_
       fp.x = x_dev;
       fp.row_stride = row_stride;
       fp.n_rows = n_rows;
-      fp.n_blocks = (n_rows + nnv::kFusedRows - 1) / nnv::kFusedRows;
+      fp.n_units = (n_rows + 31) / 32;
       fp.x16 = (row_stride % 4 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 16 == 0) ? 1 : 0;
       fp.cls32 = cls32_dev;
       fp.cls64 = cls64_dev;

@@ -29,6 +29,7 @@
 //  * The narrow class layer (<= 32 classes) runs on the vector ALU: lane = row, wave = a 1/16 slice of
 //    the inputs (weights by scalar loads), partial sums through LDS, first-maximum argmax.
 #include <mutex>
+#include <type_traits>
 
 #include "nnv_internal.h"
 
@@ -91,8 +92,17 @@ __global__ __launch_bounds__(kThreads) void wide_fused_kernel(const WideFusedPar
   };
   prefetch_layer(0);
 
-  for (int64_t blk = blockIdx.x; blk < p.n_blocks; blk += gridDim.x) {
-    const int64_t row0 = blk * kRows;
+  // Work is dealt in UNITS of 32 rows (one MFMA row tile), a contiguous range per workgroup whose sizes differ
+  // by at most one unit; a workgroup takes its units two at a time (a 64-row step: every weight fragment feeds
+  // two row tiles) and a trailing odd unit as a HALF step (the second tile's MFMAs and stores skipped).  Whole
+  // 64-row blocks dealt round-robin quantise the run to ceil(blocks / 256) steps: 1 M windows = 61.04 steps per
+  // workgroup cost 62; in units it is 61.5.
+  const int64_t u_begin = p.n_units * blockIdx.x / gridDim.x;
+  const int64_t u_end = p.n_units * (static_cast<int64_t>(blockIdx.x) + 1) / gridDim.x;
+  for (int64_t u = u_begin; u < u_end; u += 2) {
+    const int64_t row0 = u * 32;
+    const bool two = u + 1 < u_end;                  // workgroup-uniform
+    const int64_t row_end = (two ? row0 + 64 : row0 + 32) < p.n_rows ? (two ? row0 + 64 : row0 + 32) : p.n_rows;
     // ---------------- the rows' inputs -> LDS in B-operand order (layer 0's "activations") -------------
     {
       const int nq = 2 * p.groups[0];
@@ -143,27 +153,32 @@ __global__ __launch_bounds__(kThreads) void wide_fused_kernel(const WideFusedPar
         const float *bp = abuf + (h * kRows + r) * 4;
         f32x4 b0 = *reinterpret_cast<const f32x4 *>(bp);
         f32x4 b1 = *reinterpret_cast<const f32x4 *>(bp + 32 * 4);
-        auto step = [&](const f32x4 av, int g) {
-          const f32x4 c0 = b0, c1 = b1;
-          b0 = *reinterpret_cast<const f32x4 *>(bp + (g + 1) * (2 * kRows * 4));
-          b1 = *reinterpret_cast<const f32x4 *>(bp + (g + 1) * (2 * kRows * 4) + 32 * 4);
+        auto run = [&](auto two_tag) {
+          constexpr bool TWO = decltype(two_tag)::value;
+          auto step = [&](const f32x4 av, int g) {
+            const f32x4 c0 = b0, c1 = b1;
+            b0 = *reinterpret_cast<const f32x4 *>(bp + (g + 1) * (2 * kRows * 4));
+            if constexpr (TWO) b1 = *reinterpret_cast<const f32x4 *>(bp + (g + 1) * (2 * kRows * 4) + 32 * 4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], c0[e], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], c1[e], acc1, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], c0[e], acc0, 0, 0, 0);
+              if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], c1[e], acc1, 0, 0, 0);
+            }
+          };
+          int g = 0;
+          for (; g + kPrefetch <= groups; g += kPrefetch) {   // no branch inside: loads in order, waits by count
+#pragma unroll
+            for (int i = 0; i < kPrefetch; ++i) {
+              step(a[i], g + i);
+              a[i] = load_w(rsrc, tile_off + (g + i + kPrefetch) * 1024);   // AFTER its consumers: the same four registers are refilled (no copies)
+            }
           }
+#pragma unroll
+          for (int i = 0; i < kPrefetch - 1; ++i)              // the last, partial trip (uniform branches)
+            if (g + i < groups) step(a[i], g + i);
         };
-        int g = 0;
-        for (; g + kPrefetch <= groups; g += kPrefetch) {   // no branch inside: loads in order, waits by count
-#pragma unroll
-          for (int i = 0; i < kPrefetch; ++i) {
-            step(a[i], g + i);
-            a[i] = load_w(rsrc, tile_off + (g + i + kPrefetch) * 1024);   // AFTER its consumers: the same four registers are refilled (no copies)
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < kPrefetch - 1; ++i)              // the last, partial trip (uniform branches)
-          if (g + i < groups) step(a[i], g + i);
+        if (two) run(std::true_type{});
+        else run(std::false_type{});                           // half step: the first row tile only
       }
       // The NEXT layer's first fragment groups (the next 64-row block's first layer after the last one) are
       // requested now, so that their L2 round trip runs under this layer's hand-over (barrier, bias + tanh,
@@ -180,11 +195,11 @@ __global__ __launch_bounds__(kThreads) void wide_fused_kernel(const WideFusedPar
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             v0[e] = fused_act<ACT>(acc0[4 * q + e] + bias4[q][e]);
-            v1[e] = fused_act<ACT>(acc1[4 * q + e] + bias4[q][e]);
+            v1[e] = two ? fused_act<ACT>(acc1[4 * q + e] + bias4[q][e]) : 0.f;
           }
           float *dst = abuf + ((8 * wave + 2 * q + h) * kRows + r) * 4;
           *reinterpret_cast<f32x4 *>(dst) = v0;
-          *reinterpret_cast<f32x4 *>(dst + 32 * 4) = v1;
+          if (two) *reinterpret_cast<f32x4 *>(dst + 32 * 4) = v1;
         }
       }
       __syncthreads();
@@ -222,7 +237,7 @@ __global__ __launch_bounds__(kThreads) void wide_fused_kernel(const WideFusedPar
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) z += scratch[(cc * kWaves + w) * kRows + tid];
             const float v = fused_act<ACT>(z + p.head_b[c0 + cc]);   // matmul, add, activation
-            if (p.act && row < p.n_rows) p.act[row * p.n_classes + c0 + cc] = v;
+            if (p.act && row < row_end) p.act[row * p.n_classes + c0 + cc] = v;
             if (v > best) {
               best = v;
               bidx = c0 + cc;
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void wide_fused_kernel(const WideFusedPar
         }
         __syncthreads();   // scratch is reused by the next class pair; the last one also fences abuf for the next block
       }
-      if (tid < kRows && row < p.n_rows) {
+      if (tid < kRows && row < row_end) {
         if (p.cls32) p.cls32[row] = bidx;
         if (p.cls64) p.cls64[row] = bidx;
       }
@@ -263,7 +278,9 @@ nnv_status wide_fused_launch(const WideFusedParams &p, int act, int num_cus, int
       lds_set[device][act - 1] = lds_bytes;
     }
   }
-  int64_t blocks = p.n_blocks < num_cus ? p.n_blocks : num_cus;  // persistent: one workgroup per CU
+  // persistent: one workgroup per CU; short inputs: one 64-row step per workgroup
+  const int64_t steps = (p.n_units + 1) / 2;
+  int64_t blocks = steps < num_cus ? steps : num_cus;
   if (blocks < 1) blocks = 1;
   const dim3 grid(static_cast<unsigned>(blocks)), block(kThreads);
   if (act == 1) hipLaunchKernelGGL(wide_fused_kernel<1>, grid, block, lds_bytes, stream, p);
