@@ -313,6 +313,80 @@ def replayed_traffic(n_rows: int):
                                               f"not measured in this run")
 
 
+def _pmc_child(blocks_per_gpu: int) -> None:
+    """`bench.py --pmc-child`: the program rocprofv3 profiles for the live traffic figure -- the headline kernel
+    only (same network, same generated rows, 1 warm-up + 3 launches), nothing else, no child processes."""
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    cfg = fv.DecoderConfig(block_length=TILE_BITS, snr_db=SNR_DB)
+    ckpt = os.path.join(ROOT, "neural-network-based-viterbi-decoding_amd", "weights", "fnn_133171_b8_2dB.npz")
+    if os.path.exists(ckpt):
+        from nnviterbi_amd import fnn_viterbi_mixed_snr as mx
+        weights, biases = mx.load_model(ckpt)
+    else:
+        weights, biases = fv.initialize_weights(cfg, rng=np.random.RandomState(SEED))
+    Ws, bs = fv.weights_as_lists(weights, biases)
+    net = PackedMLP(Ws, bs, device=dev, precision="f32")
+    n_rows = blocks_per_gpu * ROWS_PER_BLOCK
+    x, labels = generate_awgn_blocks("133171", TILE_BITS, n_rows, float(cfg.sigma), SEED, first_row=0,
+                                     rows_per_block=ROWS_PER_BLOCK, device=dev)
+    cls = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    net.decode_timed(x, labels, cls, counters, 1, tile_bits=TILE_BITS)
+    net.decode_timed(x, labels, cls, counters, 3, tile_bits=TILE_BITS)
+    torch.cuda.synchronize(dev)
+    net.close()
+
+
+def live_traffic(blocks_per_gpu: int, timeout_s: float = 240.0):
+    """(traffic, traffic_source) MEASURED for this run: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, then
+    WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots") over a child `bench.py
+    --pmc-child` that launches the headline kernel on the same rows, on this box.  Called BEFORE this process
+    touches the GPU; the children are plain child processes (`rocprofv3 ... -- python3 bench.py ...`, counters
+    only, no tracing).  Per launch: FETCH_SIZE (KB) x 1024 x 2 (gfx950 counts 64 B per 128-B request of a wide
+    coalesced stream) + WRITE_SIZE (KB) x 1024.  Any failure returns (None, reason) and the caller replays the
+    committed profile instead."""
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    means = {}
+    work = tempfile.mkdtemp(prefix="nnv_bench_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(work, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out_dir, "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--blocks-per-gpu", str(blocks_per_gpu)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                r = subprocess.run(cmd, cwd=work, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                   timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, f"live PMC pass {ctr} exceeded {timeout_s:g} s"
+            if r.returncode != 0:
+                return None, f"live PMC pass {ctr} exited {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}"
+            vals = []
+            for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                with open(path, newline="") as f:
+                    for row in csv.DictReader(f):
+                        name = row.get("Kernel_Name", "").replace(" ", "")
+                        # the headline launches only: the fp32 LEAN instantiation of K1
+                        if "mlp_decode_kernel<0," in name and name.split("(")[0].endswith(",false,2>") \
+                                and row.get("Counter_Name") == ctr:
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"live PMC pass {ctr}: no counter rows for the headline kernel"
+            means[ctr] = (sum(vals) / len(vals), len(vals))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    traffic = means["FETCH_SIZE"][0] * 1024 * 2 + means["WRITE_SIZE"][0] * 1024
+    return traffic, (f"measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE over {means['FETCH_SIZE'][1]} launches, "
+                     f"WRITE_SIZE over {means['WRITE_SIZE'][1]}) of `bench.py --pmc-child` (the headline kernel on the same "
+                     f"rows) on this box before the timed run; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md)")
+
+
 def _stage(name: str) -> None:
     """Rank-side breadcrumb for the launching parent: which rank got how far (read only on a time-out)."""
     d = os.environ.get("NNV_BENCH_STAGE_DIR")
@@ -389,13 +463,23 @@ def main():
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("NNV_LAUNCH_TIMEOUT_S", "300")),
                     help="bare `--gpus N` only: seconds the self-launched ranks get before they are terminated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1 only: skip the two rocprofv3 --pmc child passes and replay profiles/pmc_traffic.json")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--precision", choices=("f32", "f16x3"), default="f32",   # "f16" is reported beside, never measured as `value`
                     help="f32: exact fp32 MFMA chain (headline, parity reference); "
                          "f16x3: hi/lo f16 split operands, fp32 accumulate")
     args = ap.parse_args()
 
+    if args.pmc_child:
+        _pmc_child(args.blocks_per_gpu)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, args.launch_timeout))       # nothing above touched the GPU
+    live = (None, "not attempted (N > 1, --no-live-traffic, NNV_BENCH_LIVE_TRAFFIC=0 or a non-f32 run)")
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.precision == "f32" and not args.no_live_traffic
+            and os.environ.get("NNV_BENCH_LIVE_TRAFFIC", "1") != "0" and torch.cuda.device_count() > 0):
+        live = live_traffic(args.blocks_per_gpu)                      # child processes; nothing here touched the GPU yet
 
     _stage("started")
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -534,7 +618,11 @@ def main():
         flop_row, bytes_row = algorithmic_work(dims)
         launch_s = kernel_ms / 1e3 / args.steps
         achieved = flop_row * n_rows / launch_s / 1e12
-        traffic, traffic_source = replayed_traffic(n_rows) if args.precision == "f32" else (None, "f32 profile only")
+        if live[0] is not None:
+            traffic, traffic_source = live
+        else:
+            traffic, traffic_source = replayed_traffic(n_rows) if args.precision == "f32" else (None, "f32 profile only")
+            traffic_source = f"{traffic_source}; live measurement: {live[1]}"
         out = {
             "metric": "decoded blocks/sec, (133,171) block_len=64 @ SNR 2 dB",
             "value": world * n_blocks * args.steps / elapsed,

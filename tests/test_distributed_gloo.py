@@ -229,3 +229,49 @@ def test_bench_labels_say_what_ran(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "k1_source_hash", lambda: "0" * 40)
     t, src = bench.replayed_traffic(tj["rows_per_launch"])
     assert t is None and "stale" in src
+
+
+def test_bench_live_traffic_reads_the_counters_of_the_headline_kernel(tmp_path, monkeypatch):
+    """bench.live_traffic: two `rocprofv3 --pmc` child passes, per-launch means of the fp32 LEAN K1 instantiation only,
+    FETCH_SIZE x 2 (gfx950) + WRITE_SIZE.  A stand-in `rocprofv3` on PATH writes the CSV a real pass would."""
+    import stat
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    fake = tmp_path / "bin"
+    fake.mkdir()
+    script = fake / "rocprofv3"
+    script.write_text('''#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+ctr, out = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
+assert "--" in a and a[a.index("--") + 2].endswith("bench.py") and "--pmc-child" in a
+mode = os.environ.get("FAKE_MODE", "ok")
+if mode == "fail":
+    sys.stderr.write("no counters today"); sys.exit(7)
+os.makedirs(os.path.join(out, "host", "1"), exist_ok=True)
+lean = "void nnv::mlp_decode_kernel<0, 2, 3, 4, 2, 1, 1024, false, 2>(nnv::DecodeParams)"
+other = "void nnv::mlp_decode_kernel<0, 2, 3, 4, 2, 1, 1024, false, 0>(nnv::DecodeParams)"
+f16x3 = "void nnv::mlp_decode_kernel<1, 2, 3, 4, 2, 1, 1024, false, 2>(nnv::DecodeParams)"
+val = {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 300.0}[ctr]
+rows = [] if mode == "empty" else [(lean, val - 10), (lean, val + 10), (other, 9e9), (f16x3, 9e9)]
+with open(os.path.join(out, "host", "1", "run_counter_collection.csv"), "w") as f:
+    f.write("Kernel_Name,Counter_Name,Counter_Value\\n")
+    for k, v in rows:
+        f.write('"%s",%s,%r\\n' % (k, ctr, v))
+''')
+    script.chmod(script.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(fake) + os.pathsep + os.environ["PATH"])
+    t, src = bench.live_traffic(1000, timeout_s=60)
+    assert t == 1000.0 * 1024 * 2 + 300.0 * 1024
+    assert "measured in this run" in src and "x2" in src and "over 2 launches" in src
+    monkeypatch.setenv("FAKE_MODE", "fail")
+    t, src = bench.live_traffic(1000, timeout_s=60)
+    assert t is None and "exited 7" in src and "no counters today" in src
+    monkeypatch.setenv("FAKE_MODE", "empty")
+    t, src = bench.live_traffic(1000, timeout_s=60)
+    assert t is None and "no counter rows" in src
+    monkeypatch.setenv("PATH", str(tmp_path / "nothing"))
+    t, src = bench.live_traffic(1000)
+    assert t is None and "not on PATH" in src

@@ -157,6 +157,39 @@ def test_wide_decoder_random_shapes(cuda_device, seed):
     net.close()
 
 
+@pytest.mark.parametrize("seed", range(12 * SCALE))
+def test_fused_chain_random_shapes(cuda_device, seed, monkeypatch):
+    """K6 (one persistent launch for the whole chain): random eligible shapes -- 1..7 hidden layers of width 1..512, an even
+    row length <= 512, 2..32 classes, tanh or ReLU, matrix rows or windows of a stream -- against float64 AND against the
+    layer-at-a-time path (NNV_WIDE_FUSED=0), whose hidden layers are bit-identical by construction."""
+    rng = np.random.RandomState(5000 + seed)
+    n_hidden = int(rng.randint(1, 8))
+    top = int(rng.choice([40, 130, 512]))
+    dims = [int(2 * rng.randint(1, 257))] + [int(rng.randint(1, top + 1)) for _ in range(n_hidden)] + [int(rng.randint(2, 33))]
+    activation = "relu" if seed % 3 == 2 else "tanh"
+    n = int(rng.choice([1, 31, 33, 64, 95, 1000, 3001]))
+    Ws, bs = _net(dims, rng)
+    net = WideMLP(Ws, bs, activation=activation)
+    if seed % 2 == 0:
+        stream = rng.randn(2 * (n - 1) + dims[0]).astype(np.float32)
+        x = np.stack([stream[2 * i: 2 * i + dims[0]] for i in range(n)])
+        run = lambda: net.decode_stream(torch.from_numpy(stream).cuda(), n, want_act=True)
+    else:
+        x = rng.randn(n, dims[0]).astype(np.float32)
+        xd = torch.from_numpy(x).cuda()
+        run = lambda: net.decode(xd, want_act=True)
+    monkeypatch.delenv("NNV_WIDE_FUSED", raising=False)
+    fused = run()
+    monkeypatch.setenv("NNV_WIDE_FUSED", "0")
+    layered = run()
+    monkeypatch.delenv("NNV_WIDE_FUSED", raising=False)
+    act = fused["act"].cpu().numpy()
+    _check_ff(fused["cls32"].cpu().numpy(), act, x, Ws, bs, activation)
+    scale = 1.0 if activation == "tanh" else max(1.0, float(np.abs(act).max()))
+    assert np.abs(act - layered["act"].cpu().numpy()).max() < 4e-6 * scale
+    net.close()
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("seed", range(8 * SCALE))
 def test_recurrent_decoder_random_shapes(cuda_device, seed, precision):
