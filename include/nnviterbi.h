@@ -223,8 +223,9 @@ int32_t nnv_awgn_generate_f32(int32_t code, int32_t tile_bits, int64_t n_rows,
  *   200 -> 500 -> 500 -> 500 -> 500 -> 2   src/fnn_viterbi_seq_predict.py:343-414
  * Two kernels behind one entry point:
  *  - the whole chain in ONE persistent launch, activations resident in LDS
- *    (fp32, every hidden width and the row length <= 512, <= 32 classes: the
- *    sliding-window network; no workspace traffic) -- taken automatically;
+ *    (fp32, every layer width -- class layer included -- and the row length
+ *    <= 512: the sliding-window network, feed-forward decoders with other hidden
+ *    widths; no workspace traffic) -- taken automatically;
  *  - otherwise one fp32-MFMA GEMM launch per layer (bias + activation fused),
  *    activations in the caller-provided HBM workspace, a small head kernel for
  *    <= 32 classes or a row-argmax for wider class layers.

@@ -294,8 +294,10 @@ nnv_status bitwise_f16x3_launch(const DenseF16Params &p, hipStream_t stream);
 nnv_status head_launch(const HeadParams &p, hipStream_t stream);
 
 // nnv_wide_fused.hip (K6): the whole wide network in one persistent launch, activations resident in LDS.
-// Eligible: fp32, every hidden width <= 512 (16 waves x one 32-neuron tile), row length <= 512, <= 32 classes.
-constexpr int kFusedRows = 64, kFusedThreads = 1024, kFusedMaxHidden = 7, kFusedMaxWidth = 512;
+// Eligible: fp32, every layer width -- hidden AND class layer -- and the row length <= 512 (16 waves x one
+// 32-neuron tile).  Up to 32 classes the class layer runs on the vector ALU; 33..512 classes make it one more
+// MFMA layer followed by an argmax over the LDS buffer (wide_head).
+constexpr int kFusedRows = 64, kFusedThreads = 1024, kFusedMaxHidden = 8 /* MFMA layers */, kFusedMaxWidth = 512;
 struct WideFusedParams {
   const float *x;          // row i starts at x + i * row_stride
   int64_t row_stride;
@@ -303,16 +305,17 @@ struct WideFusedParams {
   int64_t n_units;         // ceil(n_rows / 32): 32-row work units
   int32_t x16;             // every row start 16-byte aligned
   int32_t K0;              // true row length
-  int32_t n_hidden;        // layers on the matrix cores
+  int32_t n_hidden;        // layers on the matrix cores (the class layer included when wide_head)
+  int32_t wide_head;       // 1: the last MFMA layer is the class layer (33..512 classes), argmax over the LDS buffer
   int32_t groups[kFusedMaxHidden];     // ceil(K_l / 8): fragment groups (8 inputs) per neuron tile
   int32_t tiles[kFusedMaxHidden];      // ceil(M_l / 32): neuron tiles = active waves
   const float *w[kFusedMaxHidden];     // [tile][group][lane 64][4]: W[8g + 4 (lane >> 5) + e][32 tile + (lane & 31)]
   const float *bias[kFusedMaxHidden];  // [32 tiles_l], zero padded
   int32_t act_quads;       // LDS activation buffer, in k-quads of 64 rows x 16 bytes
-  int32_t head_quads;      // k-quads the class layer reads (8 tiles of the last hidden layer)
-  int32_t n_classes;       // <= 32
-  const float *head_w;     // [n_classes][4 head_quads], zero padded
-  const float *head_b;     // [n_classes]
+  int32_t head_quads;      // narrow head: k-quads it reads (8 x tiles of the last hidden layer); wide head: class quads (8 x its tiles)
+  int32_t n_classes;       // <= 32 (narrow head) or <= 512 (wide head)
+  const float *head_w;     // narrow head only: [n_classes][4 head_quads], zero padded
+  const float *head_b;     // narrow head only: [n_classes]
   int32_t *cls32;          // nullable [n_rows]
   int64_t *cls64;          // nullable [n_rows]
   float *act;              // nullable [n_rows][n_classes]

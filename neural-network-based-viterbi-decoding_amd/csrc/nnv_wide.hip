@@ -67,25 +67,29 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float *A, int64_t
   }
 }
 
-// K6 eligibility + packing.  Hidden layer l: neuron tile t, fragment group g, lane, element e holds
+// K6 eligibility + packing.  MFMA layer l: neuron tile t, fragment group g, lane, element e holds
 // W[8g + 4 (lane >> 5) + e][32 t + (lane & 31)] (zero outside the matrix): one wave-load = one contiguous 1 KB,
-// the A operand of four consecutive v_mfma_f32_32x32x2_f32.  Not eligible (fused stays 0, the layer-at-a-time
-// path runs): f16x3, a class layer wider than 32, a hidden width or row length above 512, more than 7 hidden layers.
+// the A operand of four consecutive v_mfma_f32_32x32x2_f32.  A class layer of 33..512 classes is packed as one
+// more MFMA layer (wide_head); up to 32 classes it stays a [class][input] matrix for the vector-ALU head.
+// Not eligible (fused stays 0, the layer-at-a-time path runs): f16x3, any width or the row length above 512.
 nnv_status pack_fused(const nnv_wide_desc *net, nnv_wide_handle *h) {
   h->fused = 0;
   h->fused_dev = nullptr;
   const int nh = net->depth - 1;
-  if (h->f16x3 || !h->head || nh < 1 || nh > nnv::kFusedMaxHidden) return NNV_OK;
-  if (net->dims[0] > nnv::kFusedMaxWidth) return NNV_OK;
-  for (int l = 1; l <= nh; ++l)
+  const int n_classes = net->dims[net->depth];
+  const bool wide_head = n_classes > 32;
+  const int nm = nh + (wide_head ? 1 : 0);        // layers on the matrix cores
+  if (h->f16x3 || nh < 1 || nm > nnv::kFusedMaxHidden) return NNV_OK;
+  for (int l = 0; l <= net->depth; ++l)
     if (net->dims[l] > nnv::kFusedMaxWidth) return NNV_OK;
   nnv::WideFusedParams &fp = h->fp;
   memset(&fp, 0, sizeof(fp));
-  fp.n_hidden = nh;
+  fp.n_hidden = nm;
+  fp.wide_head = wide_head ? 1 : 0;
   fp.K0 = net->dims[0];
   int64_t w_off[nnv::kFusedMaxHidden], b_off[nnv::kFusedMaxHidden], total = 0;
   int act_quads = 0;
-  for (int l = 0; l < nh; ++l) {
+  for (int l = 0; l < nm; ++l) {
     fp.groups[l] = (net->dims[l] + 7) / 8;
     fp.tiles[l] = (net->dims[l + 1] + 31) / 32;
     if (2 * fp.groups[l] > act_quads) act_quads = 2 * fp.groups[l];   // what the layer reads
@@ -96,15 +100,15 @@ nnv_status pack_fused(const nnv_wide_desc *net, nnv_wide_handle *h) {
     total += 32LL * fp.tiles[l];
   }
   fp.act_quads = act_quads;
-  fp.head_quads = 8 * fp.tiles[nh - 1];
-  fp.n_classes = net->dims[net->depth];
+  fp.head_quads = 8 * fp.tiles[nm - 1];            // narrow head: its inputs; wide head: the class quads
+  fp.n_classes = n_classes;
   const int64_t hw_off = total;
-  total += static_cast<int64_t>(fp.n_classes) * fp.head_quads * 4;
+  if (!wide_head) total += static_cast<int64_t>(n_classes) * fp.head_quads * 4;
   const int64_t hb_off = total;
-  total += round_up(fp.n_classes, 4);
+  if (!wide_head) total += round_up(n_classes, 4);
   if (nnv::wide_fused_lds_bytes(fp) > 160 * 1024) return NNV_OK;
   std::vector<float> host(static_cast<size_t>(total), 0.f);
-  for (int l = 0; l < nh; ++l) {
+  for (int l = 0; l < nm; ++l) {
     const int K = net->dims[l], M = net->dims[l + 1];
     for (int t = 0; t < fp.tiles[l]; ++t)
       for (int g = 0; g < fp.groups[l]; ++g) {
@@ -117,8 +121,8 @@ nnv_status pack_fused(const nnv_wide_desc *net, nnv_wide_handle *h) {
       }
     for (int m = 0; m < M; ++m) host[b_off[l] + m] = net->b_host[l][m];
   }
-  {
-    const int K = net->dims[nh], C = fp.n_classes;
+  if (!wide_head) {
+    const int K = net->dims[nh], C = n_classes;
     for (int c = 0; c < C; ++c)
       for (int k = 0; k < K; ++k)
         host[hw_off + static_cast<int64_t>(c) * fp.head_quads * 4 + k] = net->W_host[nh][static_cast<size_t>(k) * C + c];
@@ -131,12 +135,14 @@ nnv_status pack_fused(const nnv_wide_desc *net, nnv_wide_handle *h) {
     h->fused_dev = nullptr;
     return NNV_ERR_HIP;
   }
-  for (int l = 0; l < nh; ++l) {
+  for (int l = 0; l < nm; ++l) {
     fp.w[l] = h->fused_dev + w_off[l];
     fp.bias[l] = h->fused_dev + b_off[l];
   }
-  fp.head_w = h->fused_dev + hw_off;
-  fp.head_b = h->fused_dev + hb_off;
+  if (!wide_head) {
+    fp.head_w = h->fused_dev + hw_off;
+    fp.head_b = h->fused_dev + hb_off;
+  }
   h->fused = 1;
   return NNV_OK;
 }

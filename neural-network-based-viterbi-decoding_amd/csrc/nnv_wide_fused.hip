@@ -189,6 +189,9 @@ __global__ __launch_bounds__(kThreads) void wide_fused_kernel(const WideFusedPar
       if (active) {
         // accumulator register 4q + e <-> neuron 32 wave + 8q + 4h + e: four consecutive registers are one
         // k-quad (8 wave + 2q + h) of the next layer, i.e. one 16-byte LDS store per row and quad
+        // (Tried, round 4: dealing a narrow layer's 2 x tiles (tile, row tile) pairs one per wave so that fewer waves
+        // idle -- no gain on 14-200-96-48-128 / 16-256-128-64-256 (2.31 vs 2.27 ms, 2.97 vs 2.88 ms per 2 M rows):
+        // such networks are bound by the per-step latencies -- barriers, first loads --, not by MFMA issue; reverted.)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 v0, v1;
@@ -205,8 +208,57 @@ __global__ __launch_bounds__(kThreads) void wide_fused_kernel(const WideFusedPar
       __syncthreads();
     }
 
+    // ---------------- wide class layer (33..512 classes): it was the last MFMA layer -------------------
+    // Its activated outputs sit in the buffer like any hidden layer's; first maximum over them: lane = row,
+    // wave = a 1/16 slice of the class quads in ascending order, strict >, then the 16 partial winners in
+    // ascending slice order (so the lowest index among equal maxima wins).  Padding classes (act(0) = 0 would
+    // beat negative outputs) are masked by their index.
+    if (p.wide_head) {
+      const int qs = (p.head_quads + kWaves - 1) / kWaves;
+      const int q_lo = wave * qs;
+      const int q_hi = q_lo + qs < p.head_quads ? q_lo + qs : p.head_quads;
+      const int64_t row = row0 + lane;
+      const bool row_ok = row < row_end;
+      float best = -__builtin_inff();
+      int bidx = 0;
+      for (int q = q_lo; q < q_hi; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(abuf + (q * kRows + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 4 * q + e;
+          if (c < p.n_classes) {
+            if (p.act && row_ok) p.act[row * p.n_classes + c] = v[e];   // parity / debug output only
+            if (v[e] > best) {
+              best = v[e];
+              bidx = c;
+            }
+          }
+        }
+      }
+      int *const scratch_i = reinterpret_cast<int *>(scratch) + kWaves * kRows;
+      scratch[wave * kRows + lane] = best;
+      scratch_i[wave * kRows + lane] = bidx;
+      __syncthreads();
+      if (tid < kRows) {
+        best = -__builtin_inff();
+        bidx = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+          const float bv = scratch[w * kRows + tid];
+          const int bi = scratch_i[w * kRows + tid];
+          if (bv > best) {
+            best = bv;
+            bidx = bi;
+          }
+        }
+        if (row_ok) {                                           // tid < 64: lane == tid
+          if (p.cls32) p.cls32[row] = bidx;
+          if (p.cls64) p.cls64[row] = bidx;
+        }
+      }
+      __syncthreads();   // scratch and the buffer are free for the next block
+    } else {
     // ---------------- narrow class layer + first-maximum argmax (vector ALU) ---------------------------
-    {
       const int qs = (p.head_quads + kWaves - 1) / kWaves;   // k-quads per wave slice
       const int q_lo = wave * qs;
       const int q_hi = q_lo + qs < p.head_quads ? q_lo + qs : p.head_quads;

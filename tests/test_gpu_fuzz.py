@@ -160,12 +160,14 @@ def test_wide_decoder_random_shapes(cuda_device, seed):
 @pytest.mark.parametrize("seed", range(12 * SCALE))
 def test_fused_chain_random_shapes(cuda_device, seed, monkeypatch):
     """K6 (one persistent launch for the whole chain): random eligible shapes -- 1..7 hidden layers of width 1..512, an even
-    row length <= 512, 2..32 classes, tanh or ReLU, matrix rows or windows of a stream -- against float64 AND against the
+    row length <= 512, 2..32 classes (vector-ALU head) or 33..512 (MFMA class layer + LDS argmax), tanh or ReLU, matrix
+    rows or windows of a stream -- against float64 AND against the
     layer-at-a-time path (NNV_WIDE_FUSED=0), whose hidden layers are bit-identical by construction."""
     rng = np.random.RandomState(5000 + seed)
     n_hidden = int(rng.randint(1, 8))
     top = int(rng.choice([40, 130, 512]))
-    dims = [int(2 * rng.randint(1, 257))] + [int(rng.randint(1, top + 1)) for _ in range(n_hidden)] + [int(rng.randint(2, 33))]
+    n_classes = int(rng.randint(2, 33)) if seed % 4 < 2 else int(rng.randint(33, 513))
+    dims = [int(2 * rng.randint(1, 257))] + [int(rng.randint(1, top + 1)) for _ in range(n_hidden)] + [n_classes]
     activation = "relu" if seed % 3 == 2 else "tanh"
     n = int(rng.choice([1, 31, 33, 64, 95, 1000, 3001]))
     Ws, bs = _net(dims, rng)

@@ -261,6 +261,12 @@ FUSED_SHAPES = [
     ([10, 40, 40, 40, 40, 40, 40, 40, 7], "tanh"),  # 7 hidden layers (the most), odd class count (row strides are even)
     ([66, 30, 2], "relu"),                     # a small bit-wise style network: ReLU on every layer, logits included
     ([200, 500, 500, 2], "relu"),
+    # wide class layers (33..512 classes): one more MFMA layer + an argmax over the LDS buffer
+    ([14, 200, 96, 48, 128], "tanh"),          # the reference's b = 7 decoder with other hidden widths
+    ([16, 256, 128, 64, 256], "tanh"),
+    ([20, 64, 500], "tanh"),                   # 500 classes: 12 padding classes in the last tile must never win
+    ([16, 512, 256, 128, 512], "tanh"),        # the widest eligible class layer
+    ([30, 40, 33], "relu"),                    # 33 classes: one live class in the second tile; ReLU ties at 0 -> first index
 ]
 
 
@@ -337,9 +343,9 @@ def test_fused_chain_is_deterministic_and_row_independent(cuda_device):
 
 
 def test_shapes_outside_the_fused_kernel_take_the_layered_path(cuda_device, monkeypatch):
-    """Hidden width above 512, row length above 512, a class layer wider than 32 and the f16x3 mode are not eligible:
+    """Hidden width above 512, row length above 512, a class layer wider than 512 and the f16x3 mode are not eligible:
     the layer-at-a-time path decodes them, with or without the switch."""
-    for dims, kw in (([100, 600, 2], {}), ([1036, 30, 2], {"activation": "relu"}), ([16, 256, 128, 64, 256], {}),
+    for dims, kw in (([100, 600, 2], {}), ([1036, 30, 2], {"activation": "relu"}), ([16, 256, 128, 64, 1024], {}),
                      ([200, 500, 500, 2], {"precision": "f16x3"})):
         Ws, bs = _net(dims, 2)
         net = WideMLP(Ws, bs, **kw)
