@@ -338,14 +338,15 @@ def _pmc_child(blocks_per_gpu: int) -> None:
     net.close()
 
 
-def live_traffic(blocks_per_gpu: int, timeout_s: float = 240.0):
+def live_traffic(blocks_per_gpu: int, timeout_s: float = 90.0):
     """(traffic, traffic_source) MEASURED for this run: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, then
     WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots") over a child `bench.py
     --pmc-child` that launches the headline kernel on the same rows, on this box.  Called BEFORE this process
     touches the GPU; the children are plain child processes (`rocprofv3 ... -- python3 bench.py ...`, counters
     only, no tracing).  Per launch: FETCH_SIZE (KB) x 1024 x 2 (gfx950 counts 64 B per 128-B request of a wide
     coalesced stream) + WRITE_SIZE (KB) x 1024.  Any failure returns (None, reason) and the caller replays the
-    committed profile instead."""
+    committed profile instead.  A pass normally takes ~8 s; the time limit keeps a stuck profiler from costing the
+    run its headline line."""
     import csv
     import glob
     import shutil
