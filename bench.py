@@ -170,9 +170,10 @@ def other_baseline_configs(dev, steps: int, net_headline):
                      "class_tiles_in_lds": netm.launch_info(n)["class_tiles_in_lds"], "class_tiles": dims[-1] // 32}
         netm.close()
     # configs[3]: (133,171) block_len=1024 = 128 tiles of b=8, block i at SNR (i mod 7) dB; on-device generation
-    # INCLUDED, per-SNR-bin counters.  BASELINE names 100 M blocks over 8 GPUs (12.5 M per GPU: that share is the
-    # `-m gpu` test test_mixed_snr_sweep_full_per_gpu_share); here a reduced share, labelled so.
-    n3 = 400_000
+    # INCLUDED, per-SNR-bin counters.  BASELINE names 100 M blocks over 8 GPUs: one GPU's share, 12.5 M blocks = 1.6 G
+    # rows, generated and decoded in 32 M-row chunks (also the `-m gpu` test test_mixed_snr_sweep_full_per_gpu_share).
+    small = os.environ.get("NNV_BENCH_SMALL_LEGS") == "1"     # quick runs: the round-3 reduced sizes
+    n3 = 400_000 if small else 12_500_000                     # BASELINE: 100 M blocks over 8 GPUs = 12.5 M per GPU
     sig = [float(fv.DecoderConfig(snr_db=float(d)).sigma) for d in range(7)]
     nd.decode_blocks_sharded(net_headline, "133171", TILE_BITS, 7 * 64, 128, sig, 1, 0, 1, chunk_rows=1 << 20, device=dev)
     torch.cuda.synchronize(dev)
@@ -181,15 +182,17 @@ def other_baseline_configs(dev, steps: int, net_headline):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     c3 = c3.cpu().numpy()
-    out["configs[3]"] = {"workload": f"REDUCED: {n3} blocks on one GPU (BASELINE: 100M over 8 GPUs) -- (133,171) block_len=1024 as "
+    label3 = (f"REDUCED: {n3} blocks on one GPU (BASELINE: 100M over 8 GPUs)" if small else
+              f"ONE GPU's share of BASELINE's 100M blocks over 8 GPUs: {n3} blocks = {n3 * 128} rows")
+    out["configs[3]"] = {"workload": f"{label3} -- (133,171) block_len=1024 as "
                                      f"128 tiles of b=8, SNR of block i = i mod 7 dB, generation included, per-SNR-bin counters",
                          "value": n3 / dt, "unit": "blocks/s", "seconds": dt, "dtype": "f32",
                          "ber_by_snr_db": {str(d): float(c3[d, 0] / c3[d, 2]) for d in range(7)}}
     # configs[4]: the recurrent decoder forward.  BASELINE says GRU; the reference builds an LSTM(20) seq2seq
-    # (src/rnn_viterbi.py:289-318), and that is what runs.  1 M of the 10 M blocks (the full size is a `-m gpu` test).
+    # (src/rnn_viterbi.py:289-318), and that is what runs, at BASELINE's 10 M blocks (also a `-m gpu` test).
     from nnviterbi_amd import rnn_viterbi as rv
     from nnviterbi_amd.decoder import Seq2SeqLSTM
-    L, B4 = 256, 1_000_000
+    L, B4 = 256, (1_000_000 if small else 10_000_000)        # BASELINE: 10 M blocks (62 GB of tensors: resident)
     cfg4 = rv.RNNDecoderConfig(block_length=L, encoder_hidden_units=20)
     lstm = Seq2SeqLSTM(rv.initialize_parameters(cfg4, rng=np.random.RandomState(7)), device=dev)
     g = torch.Generator(device=dev).manual_seed(1)
@@ -208,12 +211,15 @@ def other_baseline_configs(dev, steps: int, net_headline):
     torch.cuda.synchronize(dev)
     ms4 = e0.elapsed_time(e1) / 2
     flop4 = 2 * (2 * L) * 2 * (1 + 20) * 4 * 20 + 2 * (2 * L) * 20
-    out["configs[4]"] = {"workload": f"REDUCED: {B4} of BASELINE's 10M blocks -- recurrent decoder forward, LSTM(20) seq2seq "
+    label4 = f"REDUCED: {B4} of BASELINE's 10M blocks" if small else f"BASELINE's {B4} blocks"
+    out["configs[4]"] = {"workload": f"{label4} -- recurrent decoder forward, LSTM(20) seq2seq "
                                      f"(BASELINE says GRU; the reference builds an LSTM), (133,171) block_len={L}, untrained weights",
                          "value": B4 / (ms4 * 1e-3), "unit": "blocks/s", "ms_per_launch": ms4, "dtype": "f32",
                          "roofline_frac_of_fp32_mfma_peak": flop4 * B4 / (ms4 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f32"],
                          "logits_finite": bool(torch.isfinite(r4["logits"]).all().item())}
     lstm.close()
+    del enc, dec, r4
+    torch.cuda.empty_cache()
     return out
 
 
