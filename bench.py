@@ -366,7 +366,8 @@ def live_traffic(blocks_per_gpu: int, timeout_s: float = 90.0):
             out_dir = os.path.join(work, ctr)
             cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out_dir, "-o", "run", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--blocks-per-gpu", str(blocks_per_gpu)]
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCPROF", "ROCP_"))}
+            env["TMPDIR"] = "/tmp"
             try:
                 r = subprocess.run(cmd, cwd=work, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                                    timeout=timeout_s)
@@ -483,8 +484,13 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, args.launch_timeout))       # nothing above touched the GPU
-    live = (None, "not attempted (N > 1, --no-live-traffic, NNV_BENCH_LIVE_TRAFFIC=0 or a non-f32 run)")
+    live = (None, "not attempted (N > 1, --no-live-traffic, NNV_BENCH_LIVE_TRAFFIC=0, a non-f32 run, or this process "
+                  "is itself running under a profiler)")
+    # never start a counter pass from a process that is being traced itself: the children would inherit the outer
+    # rocprofv3's tracing environment on top of their own --pmc (the combination the pool refuses)
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.precision == "f32" and not args.no_live_traffic
+            and not under_profiler
             and os.environ.get("NNV_BENCH_LIVE_TRAFFIC", "1") != "0" and torch.cuda.device_count() > 0):
         live = live_traffic(args.blocks_per_gpu)                      # child processes; nothing here touched the GPU yet
 

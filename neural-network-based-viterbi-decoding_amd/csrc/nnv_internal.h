@@ -321,6 +321,7 @@ struct WideFusedParams {
   float *act;              // nullable [n_rows][n_classes]
 };
 int64_t wide_fused_lds_bytes(const WideFusedParams &p);
+nnv_status wide_fused_prepare(const WideFusedParams &p, int act, int device);
 nnv_status wide_fused_launch(const WideFusedParams &p, int act, int num_cus, int device, hipStream_t stream);
 
 // nnv_generator.hip

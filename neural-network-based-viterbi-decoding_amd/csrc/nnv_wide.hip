@@ -143,6 +143,14 @@ nnv_status pack_fused(const nnv_wide_desc *net, nnv_wide_handle *h) {
     fp.head_w = h->fused_dev + hw_off;
     fp.head_b = h->fused_dev + hb_off;
   }
+  {
+    const nnv_status e = nnv::wide_fused_prepare(fp, h->act, h->device);
+    if (e != NNV_OK) {
+      (void)hipFree(h->fused_dev);
+      h->fused_dev = nullptr;
+      return e;
+    }
+  }
   h->fused = 1;
   return NNV_OK;
 }

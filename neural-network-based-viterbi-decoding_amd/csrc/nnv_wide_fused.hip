@@ -312,23 +312,40 @@ int64_t wide_fused_lds_bytes(const WideFusedParams &p) {
   return static_cast<int64_t>(p.act_quads) * kRows * 16 + 2LL * kWaves * kRows * 4;
 }
 
+namespace {
+// dynamic LDS above the default cap: opt in once per (device, instantiation)
+nnv_status fused_lds_optin(int act, int device, int lds_bytes) {
+  static int lds_set[kMaxDevices][2] = {};
+  static std::mutex mu;  // prepack / launches may come from several host threads
+  if (device < 0 || device >= kMaxDevices || (act != 1 && act != 2)) return NNV_ERR_INVALID_ARGUMENT;
+  const void *fn = act == 1 ? reinterpret_cast<const void *>(wide_fused_kernel<1>)
+                            : reinterpret_cast<const void *>(wide_fused_kernel<2>);
+  const std::lock_guard<std::mutex> lock(mu);
+  if (lds_set[device][act - 1] < lds_bytes) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return NNV_ERR_HIP;
+    lds_set[device][act - 1] = lds_bytes;
+  }
+  return NNV_OK;
+}
+}  // namespace
+
+// Called from nnv_wide_prepack (on the handle's device): the kernel attribute a launch of this network needs is
+// set here, so that the launches themselves are pure kernel launches -- capturable into a HIP graph from the
+// first call, like K1's (decode_prepare).
+nnv_status wide_fused_prepare(const WideFusedParams &p, int act, int device) {
+  const int64_t lds_bytes = wide_fused_lds_bytes(p);
+  if (lds_bytes > 160 * 1024) return NNV_ERR_UNSUPPORTED_SHAPE;
+  return fused_lds_optin(act, device, static_cast<int>(lds_bytes));
+}
+
 nnv_status wide_fused_launch(const WideFusedParams &p, int act, int num_cus, int device, hipStream_t stream) {
   if (p.n_rows <= 0) return NNV_OK;
   if (act != 1 && act != 2) return NNV_ERR_INVALID_ARGUMENT;
   const int lds_bytes = static_cast<int>(wide_fused_lds_bytes(p));
   if (lds_bytes > 160 * 1024) return NNV_ERR_UNSUPPORTED_SHAPE;
-  // dynamic LDS above the default cap: opt in once per (device, instantiation)
-  static int lds_set[kMaxDevices][2] = {};
-  static std::mutex mu;  // launches may come from several host threads
-  if (device < 0 || device >= kMaxDevices) return NNV_ERR_INVALID_ARGUMENT;
-  const void *fn = act == 1 ? reinterpret_cast<const void *>(wide_fused_kernel<1>)
-                            : reinterpret_cast<const void *>(wide_fused_kernel<2>);
   {
-    const std::lock_guard<std::mutex> lock(mu);
-    if (lds_set[device][act - 1] < lds_bytes) {
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return NNV_ERR_HIP;
-      lds_set[device][act - 1] = lds_bytes;
-    }
+    const nnv_status e = fused_lds_optin(act, device, lds_bytes);   // a no-op after prepack
+    if (e != NNV_OK) return e;
   }
   // persistent: one workgroup per CU; short inputs: one 64-row step per workgroup
   const int64_t steps = (p.n_units + 1) / 2;

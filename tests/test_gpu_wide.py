@@ -356,3 +356,27 @@ def test_shapes_outside_the_fused_kernel_take_the_layered_path(cuda_device, monk
         c64, _, o64 = O.decode(x, Ws, bs, 1, np.float64, activation=kw.get("activation", "tanh"))
         assert np.abs(a["act"].cpu().numpy() - o64).max() < 2e-5 * max(1.0, np.abs(o64).max())
         net.close()
+
+
+def test_fused_chain_is_hip_graph_capturable(cuda_device):
+    """K6's launch path allocates and synchronises nothing and sets no kernel attribute (prepack did): the whole
+    sliding-window decode is ONE graph node, capturable without a warm-up launch and replayable on new data."""
+    dims = [200, 500, 500, 500, 500, 2]
+    Ws, bs = _net(dims, 9)
+    net = WideMLP(Ws, bs)
+    n = 3000
+    streams = [torch.from_numpy(_stream(n, 200, 40 + k)).cuda() for k in range(2)]
+    s = streams[0].clone()
+    cls = torch.empty(n, dtype=torch.int32, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        st = net._lib.nnv_wide_decode_f32(net._handle, s.data_ptr(), n, 2, net._workspace.data_ptr(),
+                                          net._workspace.numel(), cls.data_ptr(), None, None,
+                                          torch.cuda.current_stream().cuda_stream)
+        assert st == 0
+    for src in streams:
+        s.copy_(src)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cls, net.decode_stream(src, n)["cls32"])
+    net.close()
