@@ -307,6 +307,7 @@ struct WideFusedParams {
   int32_t K0;              // true row length
   int32_t n_hidden;        // layers on the matrix cores (the class layer included when wide_head)
   int32_t wide_head;       // 1: the last MFMA layer is the class layer (33..512 classes), argmax over the LDS buffer
+  int32_t waves;           // 16 (one workgroup per CU), 8 (two per CU: every layer <= 8 tiles, LDS <= 80 KB) or 4 (four per CU)
   int32_t groups[kFusedMaxHidden];     // ceil(K_l / 8): fragment groups (8 inputs) per neuron tile
   int32_t tiles[kFusedMaxHidden];      // ceil(M_l / 32): neuron tiles = active waves
   const float *w[kFusedMaxHidden];     // [tile][group][lane 64][4]: W[8g + 4 (lane >> 5) + e][32 tile + (lane & 31)]
@@ -320,7 +321,8 @@ struct WideFusedParams {
   int64_t *cls64;          // nullable [n_rows]
   float *act;              // nullable [n_rows][n_classes]
 };
-int64_t wide_fused_lds_bytes(const WideFusedParams &p);
+int64_t wide_fused_lds_bytes(const WideFusedParams &p);   // needs p.waves
+int wide_fused_pick_waves(const WideFusedParams &p);
 nnv_status wide_fused_prepare(const WideFusedParams &p, int act, int device);
 nnv_status wide_fused_launch(const WideFusedParams &p, int act, int num_cus, int device, hipStream_t stream);
 

@@ -106,6 +106,7 @@ nnv_status pack_fused(const nnv_wide_desc *net, nnv_wide_handle *h) {
   if (!wide_head) total += static_cast<int64_t>(n_classes) * fp.head_quads * 4;
   const int64_t hb_off = total;
   if (!wide_head) total += round_up(n_classes, 4);
+  fp.waves = nnv::wide_fused_pick_waves(fp);
   if (nnv::wide_fused_lds_bytes(fp) > 160 * 1024) return NNV_OK;
   std::vector<float> host(static_cast<size_t>(total), 0.f);
   for (int l = 0; l < nm; ++l) {

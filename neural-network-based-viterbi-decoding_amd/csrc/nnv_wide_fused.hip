@@ -28,6 +28,8 @@
 //    200 exact), N to 32 (500 -> 512).
 //  * The narrow class layer (<= 32 classes) runs on the vector ALU: lane = row, wave = a 1/16 slice of
 //    the inputs (weights by scalar loads), partial sums through LDS, first-maximum argmax.
+#include <stdlib.h>
+
 #include <mutex>
 #include <type_traits>
 
@@ -42,8 +44,11 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 namespace {
 
 constexpr int kRows = kFusedRows;        // rows per workgroup step (two 32-row MFMA tiles)
-constexpr int kThreads = kFusedThreads;  // 16 waves: one neuron tile each
-constexpr int kWaves = kThreads / 64;
+// WAVES (template): 16 waves = one workgroup per CU, one neuron tile each up to 512-wide layers; or -- networks of
+// at most 256-wide (128-wide) layers whose buffers fit 80 KB (40 KB) -- 8 (4) waves and TWO (FOUR) workgroups per
+// CU, whose hand-overs (barriers, first loads, the argmax pass) then run under each other's MFMAs: a 64-row step of
+// a narrow network is mostly such latencies (14-200-96-48-128: 24 k MFMA cycles per SIMD against ~20 k of them;
+// measured 2.32 -> 1.95 ms per 2 M rows, 16-256-128-64-256 2.94 -> 2.53 ms).
 #ifndef NNV_FUSED_PREFETCH
 #define NNV_FUSED_PREFETCH 4
 #endif
@@ -61,11 +66,13 @@ __device__ __forceinline__ float fused_act(float z) {
   else return z > 0.f ? z : 0.f;
 }
 
-template <int ACT>
-__global__ __launch_bounds__(kThreads) void wide_fused_kernel(const WideFusedParams p) {
+template <int ACT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void wide_fused_kernel(const WideFusedParams p) {
+  constexpr int kWaves = WAVES;
+  constexpr int kThreads = 64 * WAVES;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *const abuf = lds;                                           // [quad][64 rows][4 floats]
-  float *const scratch = lds + static_cast<int64_t>(p.act_quads) * (kRows * 4);  // [2 classes][16 waves][64 rows]
+  float *const scratch = lds + static_cast<int64_t>(p.act_quads) * (kRows * 4);  // [2 classes][WAVES][64 rows]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // a scalar: branches / weight addresses are uniform
@@ -309,21 +316,47 @@ __global__ __launch_bounds__(kThreads) void wide_fused_kernel(const WideFusedPar
 }  // namespace
 
 int64_t wide_fused_lds_bytes(const WideFusedParams &p) {
-  return static_cast<int64_t>(p.act_quads) * kRows * 16 + 2LL * kWaves * kRows * 4;
+  return static_cast<int64_t>(p.act_quads) * kRows * 16 + 2LL * p.waves * kRows * 4;
+}
+
+// W waves x (16 / W) workgroups per CU, W the smallest of 4, 8, 16 with: every layer has at most W neuron tiles and
+// one workgroup's LDS is at most 160 KB / (16 / W).  NNV_FUSED_WAVES=16 (or 8) sets a floor (A/B runs).
+int wide_fused_pick_waves(const WideFusedParams &p) {
+  static const int floor_w = [] {
+    const char *e = getenv("NNV_FUSED_WAVES");
+    const int v = e ? atoi(e) : 0;
+    return (v == 4 || v == 8 || v == 16) ? v : 4;
+  }();
+  int max_tiles = 0;
+  for (int l = 0; l < p.n_hidden; ++l) max_tiles = p.tiles[l] > max_tiles ? p.tiles[l] : max_tiles;
+  for (const int w : {4, 8}) {
+    if (w < floor_w || max_tiles > w) continue;
+    const int64_t lds = static_cast<int64_t>(p.act_quads) * kRows * 16 + 2LL * w * kRows * 4;
+    if (lds <= (160 * 1024) / (16 / w)) return w;
+  }
+  return 16;
 }
 
 namespace {
+using FusedFn = void (*)(const WideFusedParams);
+FusedFn fused_fn(int act, int waves) {
+  if (waves == 4) return act == 1 ? wide_fused_kernel<1, 4> : wide_fused_kernel<2, 4>;
+  if (waves == 8) return act == 1 ? wide_fused_kernel<1, 8> : wide_fused_kernel<2, 8>;
+  return act == 1 ? wide_fused_kernel<1, 16> : wide_fused_kernel<2, 16>;
+}
 // dynamic LDS above the default cap: opt in once per (device, instantiation)
-nnv_status fused_lds_optin(int act, int device, int lds_bytes) {
-  static int lds_set[kMaxDevices][2] = {};
+nnv_status fused_lds_optin(int act, int waves, int device, int lds_bytes) {
+  static int lds_set[kMaxDevices][6] = {};
   static std::mutex mu;  // prepack / launches may come from several host threads
-  if (device < 0 || device >= kMaxDevices || (act != 1 && act != 2)) return NNV_ERR_INVALID_ARGUMENT;
-  const void *fn = act == 1 ? reinterpret_cast<const void *>(wide_fused_kernel<1>)
-                            : reinterpret_cast<const void *>(wide_fused_kernel<2>);
+  if (device < 0 || device >= kMaxDevices || (act != 1 && act != 2) || (waves != 4 && waves != 8 && waves != 16))
+    return NNV_ERR_INVALID_ARGUMENT;
+  const int idx = (act - 1) * 3 + (waves == 4 ? 0 : (waves == 8 ? 1 : 2));
   const std::lock_guard<std::mutex> lock(mu);
-  if (lds_set[device][act - 1] < lds_bytes) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return NNV_ERR_HIP;
-    lds_set[device][act - 1] = lds_bytes;
+  if (lds_set[device][idx] < lds_bytes) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(fused_fn(act, waves)),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+      return NNV_ERR_HIP;
+    lds_set[device][idx] = lds_bytes;
   }
   return NNV_OK;
 }
@@ -335,7 +368,7 @@ nnv_status fused_lds_optin(int act, int device, int lds_bytes) {
 nnv_status wide_fused_prepare(const WideFusedParams &p, int act, int device) {
   const int64_t lds_bytes = wide_fused_lds_bytes(p);
   if (lds_bytes > 160 * 1024) return NNV_ERR_UNSUPPORTED_SHAPE;
-  return fused_lds_optin(act, device, static_cast<int>(lds_bytes));
+  return fused_lds_optin(act, p.waves, device, static_cast<int>(lds_bytes));
 }
 
 nnv_status wide_fused_launch(const WideFusedParams &p, int act, int num_cus, int device, hipStream_t stream) {
@@ -344,16 +377,16 @@ nnv_status wide_fused_launch(const WideFusedParams &p, int act, int num_cus, int
   const int lds_bytes = static_cast<int>(wide_fused_lds_bytes(p));
   if (lds_bytes > 160 * 1024) return NNV_ERR_UNSUPPORTED_SHAPE;
   {
-    const nnv_status e = fused_lds_optin(act, device, lds_bytes);   // a no-op after prepack
+    const nnv_status e = fused_lds_optin(act, p.waves, device, lds_bytes);   // a no-op after prepack
     if (e != NNV_OK) return e;
   }
-  // persistent: one workgroup per CU; short inputs: one 64-row step per workgroup
+  // persistent: one 16-wave workgroup per CU, two 8-wave or four 4-wave ones; short inputs: one 64-row step per workgroup
   const int64_t steps = (p.n_units + 1) / 2;
-  int64_t blocks = steps < num_cus ? steps : num_cus;
+  const int64_t resident = static_cast<int64_t>(num_cus) * (16 / p.waves);
+  int64_t blocks = steps < resident ? steps : resident;
   if (blocks < 1) blocks = 1;
-  const dim3 grid(static_cast<unsigned>(blocks)), block(kThreads);
-  if (act == 1) hipLaunchKernelGGL(wide_fused_kernel<1>, grid, block, lds_bytes, stream, p);
-  else hipLaunchKernelGGL(wide_fused_kernel<2>, grid, block, lds_bytes, stream, p);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(64 * p.waves);
+  hipLaunchKernelGGL(fused_fn(act, p.waves), grid, block, lds_bytes, stream, p);
   return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 

@@ -11,7 +11,7 @@ from nnviterbi_amd import fnn_viterbi as fv
 from nnviterbi_amd.decoder import WideMLP
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
-for dims in ([14, 200, 96, 48, 128], [16, 256, 128, 64, 256], [16, 512, 256, 128, 256], [18, 512, 512, 512, 512], [200, 500, 500, 500, 500, 2]):
+for dims in ([14, 100, 100, 100, 128], [14, 200, 96, 48, 128], [16, 256, 128, 64, 256], [16, 512, 256, 128, 256], [18, 512, 512, 512, 512], [200, 500, 500, 500, 500, 2]):
     rng = np.random.RandomState(3)
     Ws = [fv.truncated_normal((dims[i], dims[i + 1]), np.sqrt(2.0 / dims[i]), rng) for i in range(len(dims) - 1)]
     bs = [(rng.randn(d) * 0.1).astype(np.float32) for d in dims[1:]]
