@@ -106,9 +106,14 @@ __global__ __launch_bounds__(64 * WAVES) void wide_fused_kernel(const WideFusedP
   // workgroup cost 62; in units it is 61.5.
   const int64_t u_begin = p.n_units * blockIdx.x / gridDim.x;
   const int64_t u_end = p.n_units * (static_cast<int64_t>(blockIdx.x) + 1) / gridDim.x;
-  for (int64_t u = u_begin; u < u_end; u += 2) {
+#ifdef NNV_FUSED_FORCE_HALF   // timing experiment only: every step ONE row tile = 4 MFMAs per weight fragment (16 B/cycle/CU from L2)
+  constexpr int kUnitStep = 1;
+#else
+  constexpr int kUnitStep = 2;
+#endif
+  for (int64_t u = u_begin; u < u_end; u += kUnitStep) {
     const int64_t row0 = u * 32;
-    const bool two = u + 1 < u_end;                  // workgroup-uniform
+    const bool two = kUnitStep == 2 && u + 1 < u_end;   // workgroup-uniform
     const int64_t row_end = (two ? row0 + 64 : row0 + 32) < p.n_rows ? (two ? row0 + 64 : row0 + 32) : p.n_rows;
     // ---------------- the rows' inputs -> LDS in B-operand order (layer 0's "activations") -------------
     {
