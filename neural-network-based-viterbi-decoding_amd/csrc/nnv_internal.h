@@ -151,19 +151,8 @@ constexpr bool kDeferArgmax = NNV_DEFER_ARGMAX != 0;
 // decode_plan (0 = A/B builds: kept in registers).
 constexpr bool kKeepLds = kDeferArgmax && NNV_KEEP_LDS != 0;
 
-// Stream variant: class M-tiles per slot of the two-slot LDS ring (mlp_decode_kernel's RT; decode_plan
-// sizes the ring from the same function).  Slot size in KB per precision; a class tile is 4 kt_out KB.
-#ifndef NNV_RING_KB_F32
-#define NNV_RING_KB_F32 8
-#endif
-#ifndef NNV_RING_KB_F16
-#define NNV_RING_KB_F16 8
-#endif
+// KB of packed weights per class M-tile: fp32 / f16x3 4 per k-tile of 32 inputs, f16 2
 constexpr int class_tile_kb(int prec, int kt_out) { return (prec == kPrecF16 ? 2 : 4) * kt_out; }
-constexpr int ring_tiles_per_slot(int prec, int kt_out) {
-  const int kb = prec == kPrecF32 ? NNV_RING_KB_F32 : NNV_RING_KB_F16;
-  return kb / class_tile_kb(prec, kt_out) >= 1 ? kb / class_tile_kb(prec, kt_out) : 1;
-}
 
 constexpr int kMaxBins = 16;
 constexpr int kLdsTailBytes = 16 + kMaxBins * 16;  // work counter + per-bin {bit, frame, rows, pad}

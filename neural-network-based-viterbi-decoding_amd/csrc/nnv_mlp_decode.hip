@@ -20,10 +20,9 @@
 //    LDS resident (one copy per CU, shared by all waves of a persistent
 //    workgroup); one ds_read_b128 feeds 4 MFMAs.  Of a class layer too large
 //    for the 160 KiB LDS as many M-tiles as fit stay resident; the rest is
-//    swept by the whole workgroup TOGETHER through a two-slot LDS ring that the
-//    waves fill by LDS-DMA (global_load_lds_dwordx4): each streamed fragment
-//    leaves L2 once per workgroup, not once per wave, and every class tile is
-//    consumed from LDS.
+//    streamed by every wave for its own row tile straight from L2 into the A
+//    operand (scalar-addressed buffer loads of the fragment-order packing, two
+//    product blocks ahead): no staging, no barrier, waves independent.
 //  * bias (the accumulator's initial value) + tanh (v_exp_f32 / v_rcp_f32) +
 //    first-max argmax on clamped pre-activations run on the VALU.  On gfx950 the
 //    fp32 MFMA shares its pipe with the VALU, so every vector instruction in the
@@ -32,9 +31,6 @@
 //  * Received soft bits are read once, as per-lane contiguous half rows
 //    (a wave reads one contiguous 32*n_in*4-byte span), prefetched one tile
 //    ahead; decoded classes are written as one 128-byte store per tile.
-#if (defined(NNV_EXPERIMENT_NO_BARRIER) || defined(NNV_EXPERIMENT_NO_DMA)) && !defined(NNV_TIMING_EXPERIMENT_BUILD)
-#error "NNV_EXPERIMENT_* compile racy kernels for timing only: build them through tools/build_variant.sh with -DNNV_TIMING_EXPERIMENT_BUILD, never into libnnviterbi_hip.so"
-#endif
 #include <type_traits>
 
 #include "nnv_internal.h"
@@ -42,8 +38,9 @@
 #ifndef NNV_CLASS_GROUP
 #define NNV_CLASS_GROUP 2
 #endif
-#ifndef NNV_RING_LATE_X
-#define NNV_RING_LATE_X 1
+// product blocks of the streamed class tiles in flight per wave (A/B builds: 1, 4; must divide the units per tile)
+#ifndef NNV_STREAM_DEPTH
+#define NNV_STREAM_DEPTH 2
 #endif
 
 namespace nnv {
@@ -303,7 +300,7 @@ __device__ unsigned long long g_diag[16];
 // VARIANT selects what the instantiation carries besides the arithmetic (cold code in the
 // persistent loop costs issue slots and registers even when it is never taken):
 //   kVarGeneral  every option of the ABI, class layer LDS resident
-//   kVarStream   + non-resident class-layer M-tiles swept by the workgroup through the LDS ring
+//   kVarStream   + non-resident class-layer M-tiles streamed from L2 by every wave for its own rows
 //   kVarLean     the benchmark / sweep call shape only: 16-byte aligned rows of an even, 4-divisible
 //                half width (p.xvec), class count a multiple of 32, classes + counters out (no
 //                int64 classes, no bit matrix, no per-SNR bins), class layer resident
@@ -338,19 +335,10 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   unsigned *bin_ctr = tile_ctr + 4;  // [kMaxBins][4] u32, used only when n_bins > 1
   if (threadIdx.x == 0) *tile_ctr = 0u;
   if (threadIdx.x < kMaxBins * 4) bin_ctr[threadIdx.x] = 0u;
-  // behind them: the argmax winner slots (64 B per thread), then (stream variant) the class-layer ring
+  // behind them: the argmax winner slots (64 B per thread)
   constexpr bool KEEP_LDS = kKeepLds;
   float *const keep_base = reinterpret_cast<float *>(bin_ctr + kMaxBins * 4);
-  constexpr int NW = NT / 64;
-  // ---- stream variant: the class-layer ring -------------------------------------------------------
-  // A slot holds RT consecutive class M-tiles (8 KB; 16 KB for KT_OUT = 4) = GPS fragment groups, which
-  // are contiguous in the packed network: one wave-level global_load_lds_dwordx4 moves one 1 KB group
-  // (per-lane source, lane-linear LDS image = the fragment-group layout itself; no VGPRs, no ds_write).
-  constexpr int RT = ring_tiles_per_slot(PREC, KT_OUT);
   constexpr int GPT = KT_OUT * KTF / kFragGroupFloats;  // fragment groups per class tile
-  constexpr int GPS = RT * GPT;                      // groups per ring slot
-  constexpr int SLOT_FLOATS = GPS * kFragGroupFloats;
-  float *const ring = keep_base + (KEEP_LDS ? NT * 16 : 0);
 
   // ---- stage the packed network into LDS (once per persistent workgroup) --
   {
@@ -379,36 +367,8 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     k = __builtin_amdgcn_readfirstlane(k);
     return static_cast<int64_t>(blockIdx.x) + static_cast<int64_t>(k) * gridDim.x;
   };
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // a scalar: branches on it are uniform
-  // Stream variant: the waves of a workgroup sweep the streamed class tiles in lock step (one barrier per
-  // ring slot), so tiles are dealt per ROUND instead: in round r wave v takes the workgroup's tile r NW + v
-  // (workgroup w owns tiles w, w + G, ...), every wave runs the same number of rounds and ring phases, and
-  // a wave without a tile in the last round only keeps the ring going (DMA + barriers).
-  int rounds = 0, n_slots = 0, round = 0;
-  int64_t total_phases = 0, phase = 0;
-  int64_t tile;
-  if constexpr (STREAM) {
-    const int64_t mine = static_cast<int64_t>(blockIdx.x) < p.n_tiles ? (p.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    rounds = static_cast<int>((mine + NW - 1) / NW);
-    n_slots = (p.mt_out - p.out_lds_tiles + RT - 1) / RT;
-    total_phases = static_cast<int64_t>(rounds) * n_slots;
-    tile = static_cast<int64_t>(blockIdx.x) + static_cast<int64_t>(wave) * gridDim.x;
-  } else {
-    tile = grab_tile();
-  }
-  // slot `slot_idx` of a round (class tiles out_lds_tiles + slot_idx RT ...) -> ring buffer `buf`
-  auto ring_fill = [&](int slot_idx, int buf) {
-    const int first = (p.out_lds_tiles + slot_idx * RT) * GPT;
-    const int last = p.mt_out * GPT - 1;  // a partial last slot re-reads the last group (valid memory, unused)
-    for (int g = wave; g < GPS; g += NW) {
-      const int gi = first + g < last ? first + g : last;
-      __builtin_amdgcn_global_load_lds(p.wpack + HIDF + static_cast<int64_t>(gi) * kFragGroupFloats + lane * 4,
-                                       ring + buf * SLOT_FLOATS + g * kFragGroupFloats, 16, 0, 0);
-    }
-  };
-  if constexpr (STREAM) {
-    if (total_phases > 0) ring_fill(0, 0);
-  }
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // a scalar
+  int64_t tile = grab_tile();
 
   unsigned bit_err = 0, frame_err = 0;
   float xr[XN];
@@ -431,9 +391,9 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   unsigned long long diag_tiles = 0;
 #endif
 
-  while (STREAM ? round < rounds : tile < p.n_tiles) {
-    const bool valid = !STREAM || tile < p.n_tiles;  // wave-uniform
-    const int64_t next_tile = STREAM ? tile + static_cast<int64_t>(NW) * gridDim.x : grab_tile();
+  while (tile < p.n_tiles) {
+    constexpr bool valid = true;   // (the round-3 ring ran waves without a tile through its barriers; gone)
+    const int64_t next_tile = grab_tile();
     float xn[XN];
     // The packed weights in LDS never change, so LLVM would hoist every
     // fragment read out of this persistent loop (and spill them).  Making the
@@ -497,7 +457,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       if constexpr (NHID == 1) {
 #pragma unroll
         for (int mt = 0; mt < MTA; ++mt) ha[mt].set(layer1_tile(mt));
-        if ((!STREAM || !NNV_RING_LATE_X || n_slots == 0) && next_tile < p.n_tiles) fetch_x(next_tile, xn);
+        if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
         NNV_STAMP(1);
       } else {
         f32x16 acc2[MTB];
@@ -512,7 +472,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
             acc2[mt] = dense_tile<PREC, 1>(a, lds + W1F + (mt * MTA + kt) * KTF + lo, acc2[mt]);
         }
         NNV_STAMP(1);  // layer 1 + layer 2 MFMAs
-        if ((!STREAM || !NNV_RING_LATE_X || n_slots == 0) && next_tile < p.n_tiles) fetch_x(next_tile, xn);
+        if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
 #pragma unroll
         for (int mt = 0; mt < MTB; ++mt) {
           act16<PREC>(acc2[mt]);
@@ -638,76 +598,56 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         finish_class_tile(acc, mt);
       }
     }
-    // Stream variant: the remaining class tiles, swept by all waves of the workgroup TOGETHER through
-    // the two-slot LDS ring.  Phase s (global count over rounds): wait for this wave's own DMA (vmcnt),
-    // barrier -- slot s has landed in buffer s & 1 for every wave and nobody still reads buffer
-    // (s + 1) & 1 --, then the DMA of slot s + 1 into that buffer (a whole phase ahead of its use), then
-    // RT class tiles of MFMAs from buffer s & 1.  Each streamed fragment leaves L2 once per workgroup and
-    // round (round 2: once per WAVE, 152 KB per row tile of configs[1], prefetched 4 MFMAs ahead) and
-    // every class tile is consumed from LDS, the path that sustains 64 cycles per MFMA.
-    //  Two things keep the phase boundary short (s_memtime stamps of the first version, plain
-    // __syncthreads() between "MFMAs + argmax" phases: 1.3 k of ~10 k cycles per phase with the matrix
-    // pipe idle).  (1) The argmax of a slot is DEFERRED to the start of the next phase: a wave reaches the
-    // barrier right after ISSUING its last MFMA -- no wait for the chain to finish, no argmax, no winner
-    // parking behind it --, and behind the barrier the previous slot's argmax runs under the latency of
-    // the first fragment read.  (2) The barrier is the RAW s_barrier behind ONE explicit s_waitcnt
-    // (__syncthreads() = fence + barrier puts its waits where the compiler's memory model wants them);
-    // the wait names exactly what the hand-over needs: vmcnt(0) for the DMA landed, lgkmcnt(0) for the
-    // ring reads returned (round 3 left the latter to instruction order; see ring_phase).
+    // Stream variant: the remaining class tiles.  Rounds 1-2 let every wave pull its own copy through plain loads one
+    // product block ahead (0.78: 64-bit vector addresses, a full wait per block); round 3 swept them through a
+    // workgroup-shared two-slot LDS ring filled by LDS-DMA, one barrier per slot (0.85: each fragment left L2 once per
+    // workgroup, but the lock step cost ~5 %).  Round 4, with what K6 (nnv_wide_fused.hip) showed -- the L2s deliver
+    // 16 B per cycle and CU to scalar-addressed buffer loads without the matrix pipe noticing --, it is per wave
+    // again, done properly: 0.905 on configs[1] (ring 0.851, same box), f16x3 324 M blocks/s (269), f16 577 M (430).
     if constexpr (STREAM) {
-      f32x16 accp;       // the LAST class tile of the slot whose MFMAs were issued before the barrier:
-      int pending = -1;  // its argmax is still pending (tile id, wave-uniform; -1: none)
-      auto retire = [&]() {
-        if (pending >= 0 && pending < p.mt_out) finish_class_tile(accp, pending);
-      };
-      // one ring phase; LAST = the round's final slot, peeled off the loop so that the NEXT round's soft
-      // bits are requested there (a phase, ~4 us, ahead of their use) instead of during the hidden layers:
-      // 4 G1 registers that would otherwise sit idle through the whole class sweep
-      auto ring_phase = [&](int i, auto last_tag) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        NNV_STAMP(4);  // resident class tiles / this phase's argmax + MFMA issue
-        // this wave's DMA of slot `phase` has landed (vmcnt), AND every ring read this wave issued in the previous
-        // phase has RETURNED (lgkmcnt): behind the barrier another wave's LDS-DMA refills that buffer, so "issued
-        // before the barrier" (all the memory clobber pins) is not enough -- the invariant is stated, not left to
-        // where the scheduler puts the last MFMAs and their own waits.  Free in practice: the reads
-        // feed MFMAs that sit in front of the barrier, so they have returned by the time the wave gets here; the
-        // parked-winner writes and bias reads of this phase were issued a whole phase (~10 k cycles) earlier.
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        NNV_STAMP(6);
-#ifndef NNV_EXPERIMENT_NO_BARRIER   // timing experiment only (races): what the lock step itself costs
-        __builtin_amdgcn_s_barrier();
-#endif
-        asm volatile("" ::: "memory");                    // no LDS access may move across the barrier
-        NNV_STAMP(7);  // all waves arrived
-        ++phase;
-#ifndef NNV_EXPERIMENT_NO_DMA       // timing experiment only (stale weights): what the ring fill costs
-        if (phase < total_phases) ring_fill(LAST ? 0 : i + 1, static_cast<int>(phase & 1));
-#endif
-        if constexpr (LAST && NNV_RING_LATE_X) {
-          if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
-        }
-        if (valid) {
-          retire();
-          const float *slot = ring + static_cast<int>((phase - 1) & 1) * SLOT_FLOATS + lo;
-          const int mtb = p.out_lds_tiles + i * RT;
-          // all but the slot's last tile are finished in the phase; only the last one (16 registers) is
-          // carried across the barrier
+      // every wave on its own: the fragment groups of the non-resident tiles are ONE linear stream (contiguous in the
+      // packed network); a UNIT is what one product block consumes (fp32: one group = 4 k-steps; f16x3: one k-step's
+      // hi + lo groups; f16: one k-step's hi group); NNV_STREAM_DEPTH units in flight, each refilled right after
+      // its consumers (same registers: no copies, waits by count)
+      constexpr int D = NNV_STREAM_DEPTH;
+      constexpr int UG = PREC == kPrecF16x3 ? 2 : 1;   // groups per unit
+      constexpr int UPT = GPT / UG;                    // units per class tile
+      static_assert(UPT % D == 0, "prefetch depth must divide the units per class tile");
+      if (valid && p.out_lds_tiles < p.mt_out) {
+        const int first = p.out_lds_tiles;
+        const int n_groups = (p.mt_out - first) * GPT;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(p.wpack + HIDF + static_cast<int64_t>(first) * GPT * kFragGroupFloats), 0, n_groups * 1024, 0x00020000);
+        const unsigned lane_off16 = static_cast<unsigned>(lane_opaque) * 16u;
+        u32x4 a[D][UG];
+        auto load_unit = [&](int u, int slot) {          // past the end: the range check returns 0 (unused)
 #pragma unroll
-          for (int t = 0; t < RT; ++t) {
-            const int mt = mtb + t < p.mt_out ? mtb + t : p.mt_out - 1;
-            f32x16 acc = dense_tile<PREC, KT_OUT>(hlast, slot + t * GPT * kFragGroupFloats, init_acc(lds + BOOFF + 32 * mt, half));
-            if (t + 1 < RT) {
-              if (mtb + t < p.mt_out) finish_class_tile(acc, mtb + t);
+          for (int k = 0; k < UG; ++k) a[slot][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off16, (u * UG + k) * 1024, 0);
+        };
+#pragma unroll
+        for (int i = 0; i < D; ++i) load_unit(i, i);
+        int u0 = 0;
+        for (int mt = first; mt < p.mt_out; ++mt) {
+          f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
+#pragma unroll
+          for (int j = 0; j < UPT; ++j) {
+            if constexpr (PREC == kPrecF32) {
+              const f32x4 av = __builtin_bit_cast(f32x4, a[j % D][0]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc = mfma32(av[e], hlast[j / 4].v[4 * (j % 4) + e], acc);
+            } else if constexpr (PREC == kPrecF16x3) {   // unit = (hi, lo) of k-step j % 2 of k-tile j / 2
+              acc = mfma16(a[j % D][1], hlast[j / 2].hi[j % 2], acc);  // small terms first
+              acc = mfma16(a[j % D][0], hlast[j / 2].lo[j % 2], acc);
+              acc = mfma16(a[j % D][0], hlast[j / 2].hi[j % 2], acc);
             } else {
-              accp = acc;
+              acc = mfma16(a[j % D][0], hlast[j / 2].hi[j % 2], acc);
             }
+            load_unit(u0 + j + D, j % D);
           }
-          pending = mtb + RT - 1;
+          u0 += UPT;
+          finish_class_tile(acc, mt);
         }
-      };
-      for (int i = 0; i + 1 < n_slots; ++i) ring_phase(i, std::false_type{});
-      if (n_slots > 0) ring_phase(n_slots - 1, std::true_type{});
-      if (valid) retire();
+      }
     }
     if constexpr (KEEP_LDS) {
 #pragma unroll
@@ -792,7 +732,6 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       for (int s = 0; s < 4 * G1; ++s) xr[s] = xn[s];
     }
     tile = next_tile;
-    ++round;
     NNV_STAMP(5);  // epilogue
 #ifdef NNV_DIAG
     ++diag_tiles;

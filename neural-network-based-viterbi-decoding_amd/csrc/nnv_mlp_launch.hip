@@ -4,6 +4,10 @@
 
 #include "nnv_internal.h"
 
+#ifndef NNV_BAND_RESIDENT_DEFAULT
+#define NNV_BAND_RESIDENT_DEFAULT 0   // see decode_configure
+#endif
+
 namespace nnv {
 
 // nnv_mlp_decode.hip compiled with -DNNV_TU_PREC=0 / =1
@@ -53,21 +57,16 @@ int pick_threads_impl(const PackedShape &s) {
     if (!k) continue;
     hipFuncAttributes attr;
     if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) continue;
-    // up to 8 spilled dwords cost less than a wave per SIMD; the stream variant's spills (fp32 9-12 dwords, f16x3
-    // 31-40) sit in per-row-tile code, outside its ring loop: configs[1], same box, fp32 0.846 at 1024 threads vs
-    // 0.79 at 512 and 0.827 at 768; f16x3 267 M blocks/s at 1024 vs 258 M at 768
-    // (1-hidden-layer stream kernels hold 64 activation registers and spill 80-150 dwords at 1024 threads: old rule)
-    if (attr.localSizeBytes <= ((s.streams && s.nhid >= 2) ? 128u : 32u)) return nt;
+    // up to 8 spilled dwords cost less than a wave per SIMD (since round 4 the stream kernels with >= 2 hidden
+    // layers spill 0-2 dwords at 1024 threads; the 1-hidden-layer ones hold 64 activation registers, spill
+    // 13-139 and fall through to 768 / 512)
+    if (attr.localSizeBytes <= 32u) return nt;
   }
   return 512;
 }
 
 
 int64_t keep_slot_bytes(int threads) { return kKeepLds ? static_cast<int64_t>(threads) * 64 : 0; }
-// two ring buffers of RT class tiles each; must match RT / GPS / SLOT_FLOATS in mlp_decode_kernel
-int64_t ring_bytes(const PackedShape &s) {
-  return 2LL * ring_tiles_per_slot(s.precision, s.kt_out) * class_tile_kb(s.precision, s.kt_out) * 1024;
-}
 
 }  // namespace
 
@@ -87,28 +86,29 @@ int decode_kernel_vgprs(const PackedShape &s, int threads, bool lean) {
 
 // Resident or streamed?  The whole network stays in LDS (general / lean variants) iff it fits beside the
 // argmax winner slots of the workgroup size pick_threads_impl chooses for the resident variant (1024 threads =
-// 64 KB of slots unless that instantiation spills); otherwise the class layer is swept through the LDS ring
-// (stream variant) at ITS workgroup size.  In between sits a band -- whole network 96..128 KB, e.g.
-// 18->128->64->32->512 (120 KB packed) -- that fits resident beside 512 threads' 32 KB of slots only.  There
-// the network stays RESIDENT at 512 threads (round 3 demoted it to the ring without trying).
-// Measured, round 4, one box, 18->128->64->32->512 over 4 M rows, two runs each (tools/bench_band.py):
-//   resident / 512 threads: fp32 2.001-2.010 ms, f16x3 0.900-0.917 ms
-//   ring / 1024 threads   : fp32 2.038-2.052 ms, f16x3 1.018-1.034 ms      (+2 % / +12 %)
-// -- unlike a 1024-class layer (configs[1]: 0.79 at 512 threads vs 0.85 through the ring at 1024), a class
-// layer this small is cheaper to keep than to sweep in lock step.  NNV_BAND_RING_1024=1 forces the ring
-// (A/B runs and the ring tests of this shape only).
+// 64 KB of slots unless that instantiation spills); otherwise as many class tiles as fit stay resident and every
+// wave streams the rest from L2 (stream variant) at ITS workgroup size.  In between sits a band -- whole network
+// 96..128 KB, e.g. 18->128->64->32->512 (120 KB packed) -- that fits resident beside 512 threads' 32 KB of slots
+// only.  Measured, round 4, one box, 18->128->64->32->512 over 4 M rows (tools/bench_band.py):
+//   stream variant at 1024 threads (every wave streams the class tiles that do not fit): fp32 1.95-1.97 ms, f16x3 0.834-0.844 ms
+//   whole network resident at 512 threads                                              : fp32 1.98-2.01 ms, f16x3 0.893-0.894 ms
+// so the band is STREAMED (earlier in round 4, against round 3's lock-step ring -- 2.04-2.05 / 1.02-1.03 ms -- the
+// resident choice had won).  NNV_BAND_RESIDENT_512=1 / NNV_BAND_STREAM_1024=1 force either (A/B runs only).
 int decode_configure(PackedShape *s, int lds_limit) {
-  static const bool band_ring_1024 = getenv("NNV_BAND_RING_1024") != nullptr;
+  static const bool band_stream = getenv("NNV_BAND_STREAM_1024") != nullptr;
+  static const bool band_resident = getenv("NNV_BAND_RESIDENT_512") != nullptr;
+  constexpr bool kBandResidentDefault = NNV_BAND_RESIDENT_DEFAULT != 0;
   const int64_t whole = (s->hid_floats + s->out_floats + s->bias_floats) * 4 + kLdsTailBytes;
   s->streams = 0;
   const int t = pick_threads_impl(*s);
   if (whole + keep_slot_bytes(t) <= lds_limit) return t;
-  if (!band_ring_1024 && t > 512 && whole + keep_slot_bytes(512) <= lds_limit) return 512;
+  const bool resident_512 = band_resident || (kBandResidentDefault && !band_stream);
+  if (resident_512 && t > 512 && whole + keep_slot_bytes(512) <= lds_limit) return 512;
   s->streams = 1;
-  // ring-swept: hidden layers + biases + winner slots + ring must fit; a network with a very large class
-  // layer's biases (4096 classes: 16 KB) falls back to 512 threads (half the winner slots)
+  // streamed: hidden layers + biases + winner slots must fit; a network with a very large class layer's biases
+  // (4096 classes: 16 KB) falls back to 512 threads (half the winner slots)
   int ts = pick_threads_impl(*s);
-  const int64_t fixed = (s->hid_floats + s->bias_floats) * 4 + kLdsTailBytes + ring_bytes(*s);
+  const int64_t fixed = (s->hid_floats + s->bias_floats) * 4 + kLdsTailBytes;
   if (fixed + keep_slot_bytes(ts) > lds_limit && ts > 512 && fixed + keep_slot_bytes(512) <= lds_limit) ts = 512;
   return ts;
 }
@@ -117,17 +117,18 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
                        int lds_limit, int threads, LaunchPlan *plan) {
   if (!find_kernel(s, 512, false)) return NNV_ERR_UNSUPPORTED_SHAPE;
   const int64_t base_floats = s.hid_floats + s.bias_floats;
-  // Every variant parks the running argmax winner's accumulators in LDS, 64 bytes per thread.  The stream
-  // variant adds the two-slot class-layer ring (8 KB slots, 16 KB for 128-wide last hidden layers): with
-  // the ring a streamed class tile costs one barrier per slot and one DMA, so residency matters little and
-  // the LDS is better spent on the slots than on more resident class tiles (round 2, per-wave streaming,
-  // had it the other way round: 13 of 32 tiles resident, winner kept by 16 v_cndmask per class tile).
-  const int64_t scratch = keep_slot_bytes(threads) + (s.streams ? ring_bytes(s) : 0);
+  // Every variant parks the running argmax winner's accumulators in LDS, 64 bytes per thread; the rest of the LDS
+  // holds as many class-layer M-tiles as fit (all of them unless this is the stream variant).
+  const int64_t scratch = keep_slot_bytes(threads);
   if (base_floats * 4 + kLdsTailBytes + scratch > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
-  // as many class-layer M-tiles as fit stay in LDS; the remaining ones go through the ring
+  // as many class-layer M-tiles as fit stay in LDS; every wave streams the remaining ones from L2
   const int64_t per_tile_bytes = static_cast<int64_t>(class_tile_kb(s.precision, s.kt_out)) * 1024;
   int64_t fit = (lds_limit - kLdsTailBytes - scratch - base_floats * 4) / per_tile_bytes;
   if (fit > s.mt_out) fit = s.mt_out;
+  if (s.streams) {  // A/B runs only: cap the resident class tiles of the stream variant
+    static const int cap = [] { const char *e = getenv("NNV_STREAM_MAX_RESIDENT"); return e ? atoi(e) : -1; }();
+    if (cap >= 0 && fit > cap) fit = cap;
+  }
   if (s.streams == 0 && fit < s.mt_out) return NNV_ERR_UNSUPPORTED_SHAPE;  // decode_configure sized it
   plan->out_lds_tiles = static_cast<int32_t>(fit);
   plan->out_in_lds = fit == s.mt_out ? 1 : 0;

@@ -77,7 +77,7 @@ def test_fused_decoder_random_shapes(cuda_device, seed, precision):
 @pytest.mark.parametrize("seed", range(6 * SCALE))
 def test_fused_decoder_random_shapes_many_rows(cuda_device, seed, precision):
     """K1 over SEVERAL rounds of its persistent workgroups (40 k - 150 k rows: every wave of every workgroup decodes
-    more than one row tile, ragged tails), class counts up to 4096 so that the resident, lean and ring-swept variants
+    more than one row tile, ragged tails), class counts up to 4096 so that the resident, lean and stream variants
     all occur.  Every row against the C oracle; rows that differ must be float64 near-ties."""
     rng = np.random.RandomState(5000 + seed)
     n_hidden = rng.randint(1, 4)

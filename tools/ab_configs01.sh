@@ -7,6 +7,7 @@ for lib in "$@"; do
 import json,sys
 for line in open("/tmp/abc.json"):
     d=json.loads(line)
-    print(f"{sys.argv[1]:22s} {d['config']} f32 {d['f32']['ms_per_launch']:.4f} ms frac {d['f32']['frac_of_peak']:.4f} lds_tiles {d['f32']['class_tiles_in_lds']} | f16x3 {d['f16x3']['ms_per_launch']:.4f} ms {d['f16x3']['value']/1e6:.1f} Mblk/s lds_tiles {d['f16x3']['class_tiles_in_lds']}")
+    f16 = d.get("f16", {})
+    print(f"{sys.argv[1]:22s} {d['config']} f32 {d['f32']['ms_per_launch']:.4f} ms frac {d['f32']['frac_of_peak']:.4f} lds_tiles {d['f32']['class_tiles_in_lds']} | f16x3 {d['f16x3']['ms_per_launch']:.4f} ms {d['f16x3']['value']/1e6:.1f} Mblk/s lds_tiles {d['f16x3']['class_tiles_in_lds']} | f16 {f16.get('ms_per_launch', 0):.4f} ms {f16.get('value', 0)/1e6:.1f} Mblk/s")
 PY
 done
