@@ -134,8 +134,8 @@ def cpu_baseline(x_dev, labels_dev, Ws, bs, hip_cls, budget_s=12.0, torch_budget
 def other_baseline_configs(dev, steps: int, net_headline):
     """The other four BASELINE configs measured in the same run (never `value`; 3 and 4 at reduced size, labelled).
     configs[0] and configs[1]: (7,5) K=3 at block_len 20 / 100 as
-    b = 10 tiles, network 20-128-64(-32)-1024 -- the 1024-class layer does not fit the LDS and is swept by each
-    workgroup through an LDS ring (K1's stream variant).  Matched-filter weights of the reference's
+    b = 10 tiles, network 20-128-64(-32)-1024 -- the 1024-class layer does not fit the LDS: the tiles that do not
+    fit are streamed from L2 by every wave for its own rows (K1's stream variant).  Matched-filter weights of the reference's
     architecture (pass-through hidden layers, class layer = correlation with every codeword), so that the BER is the
     code's and not an untrained network's; exact fp32; HIP events around `steps` launches."""
     out = {}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The 96-128 KB band of K1: a network that fits the LDS beside 512 threads' winner slots but not
-beside 1024 threads' -- e.g. 18->128->64->32->512 (120 KB packed).  Default: class layer through the LDS ring at
-1024 threads; NNV_BAND_STREAM_1024=1 (read once per process): class layer streamed at 1024 threads instead of the whole network resident at 512.
+beside 1024 threads' -- e.g. 18->128->64->32->512 (120 KB packed).  Default: class layer streamed at 1024 threads;
+NNV_BAND_RESIDENT_512=1 (read once per process): the whole network resident at 512 threads instead.
 Run once per setting in ONE gpurun call (box-to-box spread is ~1 %).  One JSON line."""
 import json, os, sys
 import numpy as np, torch
@@ -19,7 +19,7 @@ bs = [(rng.randn(d) * 0.1).astype(np.float32) for d in dims[1:]]
 x = torch.randn(n, dims[0], device="cuda", generator=torch.Generator("cuda").manual_seed(1))
 lab = torch.zeros(n, dtype=torch.int32, device="cuda")
 flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
-out = {"net": dims, "rows": n, "NNV_BAND_STREAM_1024": os.environ.get("NNV_BAND_STREAM_1024")}
+out = {"net": dims, "rows": n, "NNV_BAND_RESIDENT_512": os.environ.get("NNV_BAND_RESIDENT_512")}
 for prec in ("f32", "f16x3"):
     net = PackedMLP(Ws, bs, precision=prec)
     cls = torch.empty(n, dtype=torch.int32, device="cuda")

@@ -2,7 +2,7 @@
 """Secondary benchmark (NOT the headline; bench.py is): BASELINE configs[0] and configs[1], the (7,5)
 K=3 code at block_len 20 (1k blocks, 3-layer FNN) and block_len 100 (1M blocks @ SNR 4 dB, 2-layer FNN).
 Tiling rule: b = 10 divides both -> 2 / 10 tiles per block, net 20 -> 128 -> 64 (-> 32) -> 1024; the class
-layer (256 / 128 KiB) exceeds the LDS: a few M-tiles stay resident, the rest is swept by the workgroup through an LDS ring.
+layer (256 / 128 KiB) exceeds the LDS: as many M-tiles as fit stay resident, every wave streams the rest from L2 for its own rows.
 Weights: a matched-filter network of the reference's architecture (pass-through hidden layers, class layer =
 correlation with every codeword: the ML decision per tile); throughput does not depend on the weights.
 Prints one JSON line per config.  Usage: python tools/bench_configs01.py [--steps 20]"""
