@@ -26,6 +26,11 @@ struct nnv_bitwise_handle {
   float *dev;      // f32:   Wt [mpad][kpad] | bias [mpad] | head_w [n_pos][32][2] | head_b [n_pos][2]
                    // f16x3: W_hi [mpad][kpad] f16 | W_lo [mpad][kpad] f16 (together the bytes of the fp32 matrix) | bias | ...
   int64_t off_bias, off_hw, off_hb;
+  // K4c (nnv_bitwise_stream.hip): rows resident in LDS, first layers streamed from L2 -- the fp32 bank's default
+  int32_t stream_ok;   // 1: stream_dev holds the fragment-order packing of the first layers
+  int32_t num_cus;
+  int32_t groups;      // ceil(n_input / 8)
+  float *stream_dev;   // [pos][group][lane][4]
 };
 
 extern "C" {
@@ -101,6 +106,36 @@ int32_t nnv_bitwise_prepack_ex(const nnv_bitwise_desc *d, int32_t precision, nnv
     delete h;
     return NNV_ERR_HIP;
   }
+  // K4c packing: position p, fragment group g, lane, element e holds W1[p][8g + 4 (lane >> 5) + e][lane & 31]
+  h->stream_ok = 0;
+  h->stream_dev = nullptr;
+  h->num_cus = prop.multiProcessorCount;
+  h->groups = static_cast<int32_t>((K + 7) / 8);
+  const int64_t frag_floats = P * h->groups * 256;
+  if (precision == NNV_PRECISION_F32 && P >= 2 && nnv::bank_stream_lds_bytes(h->groups) <= 160 * 1024 &&
+      frag_floats * 4 < (1LL << 31)) {
+    std::vector<float> frag(static_cast<size_t>(frag_floats), 0.f);
+    for (int64_t pos = 0; pos < P; ++pos) {
+      const float *W1 = d->W1_host + pos * K * H;
+      for (int64_t g = 0; g < h->groups; ++g) {
+        float *grp = frag.data() + (pos * h->groups + g) * 256;
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 4; ++e) {
+            const int64_t k = 8 * g + 4 * (lane >> 5) + e, j = lane & 31;
+            if (k < K && j < H) grp[lane * 4 + e] = W1[k * H + j];
+          }
+      }
+    }
+    if (hipMalloc(reinterpret_cast<void **>(&h->stream_dev), frag.size() * sizeof(float)) == hipSuccess) {
+      if (hipMemcpy(h->stream_dev, frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+          nnv::bank_stream_prepare(h->groups, dev) == NNV_OK) {
+        h->stream_ok = 1;
+      } else {
+        (void)hipFree(h->stream_dev);
+        h->stream_dev = nullptr;
+      }
+    }
+  }
   *out = h;
   return NNV_OK;
 }
@@ -108,8 +143,9 @@ int32_t nnv_bitwise_prepack_ex(const nnv_bitwise_desc *d, int32_t precision, nnv
 int32_t nnv_bitwise_free(nnv_bitwise_handle *h) {
   if (!h) return NNV_OK;
   const hipError_t e = hipFree(h->dev);
+  const hipError_t e2 = h->stream_dev ? hipFree(h->stream_dev) : hipSuccess;
   delete h;
-  return e == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+  return (e == hipSuccess && e2 == hipSuccess) ? NNV_OK : NNV_ERR_HIP;
 }
 
 int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, int64_t n_rows,
@@ -123,6 +159,32 @@ int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, 
   {
     const nnv_status dv = nnv::check_current_device(h->device);
     if (dv != NNV_OK) return dv;
+  }
+  // K4c: rows resident in LDS, first layers streamed (fp32 banks of >= 2 positions).  NNV_BANK_STREAM=0, read per
+  // call, keeps the LDS-tiled GEMM (K4b) for A/B runs and for the tests that hold the two against each other.
+  if (h->stream_ok) {
+    const char *e = getenv("NNV_BANK_STREAM");
+    if (!(e && e[0] == '0')) {
+      nnv::BankStreamParams q{};
+      q.x = x_dev;
+      q.row_stride = h->n_input;
+      q.n_rows = n_rows;
+      q.n_blocks = (n_rows + 31) / 32;
+      q.x16 = (h->n_input % 4 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 16 == 0) ? 1 : 0;
+      q.K = h->n_input;
+      q.groups = h->groups;
+      q.n_pos = h->n_pos;
+      q.w_bytes = static_cast<int32_t>(static_cast<int64_t>(h->n_pos) * h->groups * 1024);
+      q.w = h->stream_dev;
+      q.bias = h->dev + h->off_bias;
+      q.head_w = h->dev + h->off_hw;
+      q.head_b = h->dev + h->off_hb;
+      q.bits = bits_dev;
+      q.head_act = act_dev;
+      q.labels = labels_dev;
+      q.errors = reinterpret_cast<unsigned long long *>(errors_dev);
+      return nnv::bank_stream_launch(q, h->num_cus, h->device, static_cast<hipStream_t>(stream));
+    }
   }
   nnv::DenseParams p{};
   p.A = x_dev;

@@ -315,6 +315,32 @@ int wide_fused_pick_waves(const WideFusedParams &p);
 nnv_status wide_fused_prepare(const WideFusedParams &p, int act, int device);
 nnv_status wide_fused_launch(const WideFusedParams &p, int act, int num_cus, int device, hipStream_t stream);
 
+// nnv_bitwise_stream.hip (K4c): the bit-wise bank with 32 received rows resident in LDS and every position's first
+// layer streamed from L2 into the MFMA A operand.  Eligible: fp32, >= 2 positions, n_hidden <= 32, LDS for one row tile
+// ((2 ceil(n_input / 8) + 2) KB) <= 160 KB, packed first layers < 2 GB.
+struct BankStreamParams {
+  const float *x;          // [n_rows][row_stride]
+  int64_t row_stride;
+  int64_t n_rows;
+  int64_t n_blocks;        // ceil(n_rows / 32)
+  int32_t x16;             // every row start 16-byte aligned
+  int32_t K;               // n_input
+  int32_t groups;          // ceil(K / 8)
+  int32_t n_pos;
+  int32_t w_bytes;         // n_pos * groups * 1024
+  const float *w;          // [pos][group][lane 64][4]: W1[pos][8g + 4 (lane >> 5) + e][lane & 31], zero padded
+  const float *bias;       // [pos][32]
+  const float *head_w;     // [pos][32 hidden][2 outputs]
+  const float *head_b;     // [pos][2]
+  uint8_t *bits;           // [n_pos][n_rows]
+  float *head_act;         // nullable [n_pos][n_rows][2]
+  const uint8_t *labels;   // nullable [n_pos][n_rows]
+  unsigned long long *errors;  // nullable [n_pos], ACCUMULATED (needs labels)
+};
+int64_t bank_stream_lds_bytes(int groups);
+nnv_status bank_stream_prepare(int groups, int device);
+nnv_status bank_stream_launch(const BankStreamParams &p, int num_cus, int device, hipStream_t stream);
+
 // nnv_generator.hip
 nnv_status generate_launch(int32_t code, int32_t tile_bits, int64_t n_rows,
                            int64_t first_row, int64_t rows_per_block,

@@ -99,3 +99,31 @@ def test_bank_argument_validation(cuda_device):
     with pytest.raises(Exception):
         BitwiseBank([(np.zeros((60, 40), np.float32), np.zeros(40, np.float32),       # n_hidden > 32
                       np.zeros((40, 2), np.float32), np.zeros(2, np.float32))])
+
+
+@pytest.mark.parametrize("block_length,n_pos,n_rows", [(512, 40, 1500), (24, 24, 777), (25, 17, 129), (40, 3, 1),
+                                                       (100, 33, 4099)])
+def test_streamed_bank_equals_the_tiled_bank_bit_for_bit(cuda_device, monkeypatch, block_length, n_pos, n_rows):
+    """K4c (rows resident in LDS, every position's first layer streamed from L2; the fp32 bank's default since round 4)
+    against K4b (LDS-tiled GEMM, NNV_BANK_STREAM=0, read per call): the same k order in the first layer and the same
+    sequential 32-term head chain, so decided bits, ReLU'd outputs and error counters are IDENTICAL, not just close."""
+    cfg = bw.BitwiseDecoderConfig(block_length=block_length, training_size=4, test_size=n_rows, test_snr_index=3)
+    np.random.seed(3 * block_length + n_pos)
+    info, enc = bw.generate_test_data(cfg)
+    models = _models(cfg, n_pos, seed=21)
+    x = torch.from_numpy(enc.astype(np.float32)).cuda()
+    labels = torch.from_numpy(np.ascontiguousarray(np.resize(info.T, (n_pos, n_rows)).astype(np.uint8))).cuda()
+    bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models], precision="f32")
+    monkeypatch.delenv("NNV_BANK_STREAM", raising=False)
+    a = bank.decode(x, labels=labels, want_act=True)
+    monkeypatch.setenv("NNV_BANK_STREAM", "0")
+    b = bank.decode(x, labels=labels, want_act=True)
+    monkeypatch.delenv("NNV_BANK_STREAM", raising=False)
+    assert torch.equal(a["bits"], b["bits"]) and torch.equal(a["act"], b["act"]) and torch.equal(a["errors"], b["errors"])
+    # and a view of x that starts 8 bytes into an allocation (rows 8-byte aligned only)
+    if enc.shape[1] % 4 == 2:
+        pad = torch.empty(x.numel() + 2, dtype=torch.float32, device="cuda")
+        pad[2:] = x.reshape(-1)
+        c = bank.decode(pad[2:].view_as(x), labels=labels, want_act=True)
+        assert torch.equal(c["bits"], a["bits"]) and torch.equal(c["act"], a["act"])
+    bank.close()

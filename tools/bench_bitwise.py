@@ -61,7 +61,11 @@ for p in range(P):
     wp, bp = bw.initialize_weights(cfg, rng=np.random.RandomState(100 + p))
     models.append((wp["h1"], bp["b1"], wp["out"], np.array([0.01, 0.0], np.float32)))
 bank = BitwiseBank(models)
-msP, rP = timed(lambda: bank.decode(x), max(2, args.steps // 4))
+msP, rP = timed(lambda: bank.decode(x), max(2, args.steps // 4))        # K4c: rows resident in LDS, first layers streamed
+os.environ["NNV_BANK_STREAM"] = "0"                                      # K4b: the LDS-tiled GEMM (read per call)
+msPt, rPt = timed(lambda: bank.decode(x), max(2, args.steps // 4))
+del os.environ["NNV_BANK_STREAM"]
+tiled_same = bool(torch.equal(rPt["bits"], rP["bits"]))
 bitsP = rP["bits"][:, :m].cpu().numpy()
 mismP = 0
 for p in (0, P // 2, P - 1):
@@ -115,6 +119,9 @@ print(json.dumps({
                      "unit": "TFLOP/s", "frac": flop_row * n / (msP * 1e-3) / 157.3e12,
                      "algorithmic_flop_per_row": flop_row, "algorithmic_bytes_per_row": bytes_row,
                      "hbm_frac_of_8TBs": bytes_row * n / (msP * 1e-3) / 8.0e12},
+        "kernel": "K4c bank_stream_kernel (32 rows resident in LDS, every position's first layer streamed from L2)",
+        "tiled_gemm_K4b": {"ms_per_step": msPt, "frac": flop_row * n / (msPt * 1e-3) / 157.3e12,
+                           "decided_bits_identical": tiled_same},
         "speedup_vs_one_launch_per_position": ms1 * P / msP,
         "parity_sample": {"rows": m, "positions_checked": 3, "class_mismatches": mismP},
     },
