@@ -630,7 +630,7 @@ def _content_snapshot(tensors: List[torch.Tensor]) -> torch.Tensor:
     return torch.cat(flat).view(torch.int32)
 
 
-def _cached_pack(weights: List[torch.Tensor], biases: List[torch.Tensor], device) -> PackedMLP:
+def _cached_pack(weights: List[torch.Tensor], biases: List[torch.Tensor], device):
     from torch.multiprocessing.reductions import StorageWeakRef
     tensors = list(weights) + list(biases)
     precision = _resolve_precision(None)
@@ -648,9 +648,42 @@ def _cached_pack(weights: List[torch.Tensor], biases: List[torch.Tensor], device
         _evict(key)                                   # same storages, written in place since
     while len(_PACK_CACHE) >= _PACK_CACHE_MAX:
         _evict(next(iter(_PACK_CACHE)))               # least recently used
-    net = PackedMLP(weights, biases, device=device, precision=precision)
+    try:
+        net = PackedMLP(weights, biases, device=device, precision=precision)
+    except NNViterbiError as e:
+        # hidden widths the register-chained kernel has no instantiation for (they are free parameters of the
+        # reference's DecoderConfig): the same ops run through the wide path -- one persistent launch for the whole
+        # chain up to 512-wide layers (K6), one launch per layer beyond -- still on the GPU, same tolerances
+        if "unsupported network shape" not in str(e):
+            raise
+        net = WideMLP(weights, biases, device=device, precision=precision if len(biases[-1]) <= 32 else "f32")
     _PACK_CACHE[key] = _PackEntry(net, [StorageWeakRef(st) for st in storages], versions, snapshot)
     return net
+
+
+def _decode_with(net, x: torch.Tensor, tile_bits: int, labels: Optional[torch.Tensor]):
+    """(cls64, bits, counters) from either kind of packed network.  PackedMLP's fused kernel emits all three; the wide
+    path emits the classes and the rest is integer work on them (MSB-first bits, src/fnn_viterbi.py:648-651; error
+    counters :639,654-671)."""
+    if isinstance(net, PackedMLP):
+        r = net.decode(x, labels=labels, tile_bits=tile_bits, want_cls32=False, want_cls64=True, want_bits=True)
+        counters = r["counters"]
+        if counters is None:
+            counters = torch.zeros(4, dtype=torch.int64, device=x.device)
+        return r["cls64"], r["bits"], counters
+    if not x.is_contiguous():
+        x = x.contiguous()
+    cls = net.decode(x, want_cls64=True)["cls64"]
+    shifts = torch.arange(tile_bits - 1, -1, -1, dtype=torch.int64, device=x.device)
+    bits = ((cls[:, None] >> shifts[None, :]) & 1).to(torch.uint8)
+    counters = torch.zeros(4, dtype=torch.int64, device=x.device)
+    if labels is not None:
+        diff = cls ^ labels.to(torch.int64)
+        counters[0] = ((diff[:, None] >> shifts[None, :]) & 1).sum()
+        counters[1] = (diff != 0).sum()
+        counters[2] = x.shape[0] * tile_bits
+        counters[3] = x.shape[0]
+    return cls, bits, counters
 
 
 def _forward_torch(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.Tensor]) -> torch.Tensor:
@@ -684,13 +717,8 @@ def mlp_decode(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.
                tile_bits: int, labels: Optional[torch.Tensor] = None
                ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """(cls int64 [N], bits uint8 [N, b], counters int64 [4]) - HIP kernel."""
-    net = _cached_pack(list(weights), list(biases), x.device)
-    r = net.decode(x, labels=labels, tile_bits=tile_bits, want_cls32=False,
-                   want_cls64=True, want_bits=True)
-    counters = r["counters"]
-    if counters is None:
-        counters = torch.zeros(4, dtype=torch.int64, device=x.device)
-    return r["cls64"], r["bits"], counters
+    _check_op_args(x, weights, biases, tile_bits, labels)
+    return _decode_with(_cached_pack(list(weights), list(biases), x.device), x, tile_bits, labels)
 
 
 @mlp_decode.register_kernel("cpu")
@@ -724,7 +752,10 @@ def _(x, weights, biases, tile_bits, labels=None):
 def mlp_forward(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.Tensor]) -> torch.Tensor:
     """multilayer_perceptron(x, weights, biases) (src/fnn_viterbi.py:471-510): the tanh'd class layer
     [N, n_classes] float32 - debug / parity op."""
-    return _cached_pack(list(weights), list(biases), x.device).forward(x)
+    net = _cached_pack(list(weights), list(biases), x.device)
+    if isinstance(net, PackedMLP):
+        return net.forward(x)
+    return net.decode(x if x.is_contiguous() else x.contiguous(), want_act=True)["act"]
 
 
 @mlp_forward.register_kernel("cpu")

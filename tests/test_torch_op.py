@@ -273,3 +273,29 @@ def test_optimizer_step_behind_the_data_idiom_is_decoded_with_the_new_weights(cu
         params[0].data.mul_(-1.0)                 # a write no counter records at all
     assert torch.equal(op(), fresh())
     decoder.clear_pack_cache()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,b", [([14, 200, 96, 48, 128], 7), ([16, 256, 128, 64, 256], 8), ([20, 300, 1024], 10)])
+def test_op_takes_networks_of_other_hidden_widths(cuda_device, dims, b):
+    """The reference's n_hidden_* are free parameters: shapes the register-chained kernel has no instantiation for must
+    not make the OP fail -- it runs them through the wide path (one persistent launch for the whole chain up to
+    512-wide layers, one launch per layer beyond), same schema, same contract, cache included."""
+    rng = np.random.RandomState(len(dims) + b)
+    Ws = [(rng.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+    bs = [(rng.randn(d) * 0.1).astype(np.float32) for d in dims[1:]]
+    x = rng.randn(3001, dims[0]).astype(np.float32)
+    labels = rng.randint(0, dims[-1], 3001).astype(np.int32)
+    decoder.clear_pack_cache()
+    g_cls, g_bits, g_cnt = torch.ops.nnviterbi.mlp_decode(torch.from_numpy(x).cuda(), _t(Ws, "cuda"), _t(bs, "cuda"), b,
+                                                          torch.from_numpy(labels).cuda())
+    g_out = torch.ops.nnviterbi.mlp_forward(torch.from_numpy(x).cuda(), _t(Ws, "cuda"), _t(bs, "cuda"))
+    assert isinstance(next(iter(decoder._PACK_CACHE.values())).net, decoder.WideMLP)
+    c64, _, o64 = O.decode(x, Ws, bs, b, np.float64)
+    cls = g_cls.cpu().numpy()
+    assert np.abs(g_out.cpu().numpy() - o64).max() < TOL
+    bad = cls != c64
+    assert not bad.any() or O.top2_margin(o64)[bad].max() < TOL
+    assert np.array_equal(g_bits.cpu().numpy(), O.class_to_bits(cls, b))
+    assert np.array_equal(g_cnt.cpu().numpy(), O.error_counters(cls, labels, b))
+    decoder.clear_pack_cache()
