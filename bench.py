@@ -264,8 +264,50 @@ def next_row_paths(dev, steps: int):
                      "ones_decoded": int(r["cls32"].sum().item())}
     net.close()
     res["classes_differing_between_the_two_paths"] = None if len({v["ones_decoded"] for v in res.values()}) == 1 else "see ones_decoded"
-    return {"sliding_window": {"workload": f"{n} windows of 200 over one received stream, {'-'.join(str(d) for d in dims)} tanh, "
-                                           f"{flop} FLOP per decoded bit, exact fp32, untrained weights", **res}}
+    out = {"sliding_window": {"workload": f"{n} windows of 200 over one received stream, {'-'.join(str(d) for d in dims)} tanh, "
+                                          f"{flop} FLOP per decoded bit, exact fp32, untrained weights", **res}}
+    del stream
+    # the bit-wise decoder (src/fnn_viterbi_bitwise.py:326-399,503-505: one 2(6+L) -> 30 -> 2
+    # ReLU network per information-bit position, evaluated one per run by the reference) as a BANK: all 512 positions of
+    # the reference's default block length over its default 300,000 test rows in one launch.  K4c = rows resident in LDS,
+    # every position's first layer streamed from L2 (csrc/nnv_bitwise_stream.hip); K4b = the LDS-tiled GEMM beside it.
+    from nnviterbi_amd import fnn_viterbi_bitwise as bw
+    from nnviterbi_amd.decoder import BitwiseBank
+    cfgb = bw.BitwiseDecoderConfig()
+    P, nb = cfgb.block_length, 300_000
+    models = []
+    for pos in range(P):
+        wp, bp = bw.initialize_weights(cfgb, rng=np.random.RandomState(100 + pos))
+        models.append((wp["h1"], bp["b1"], wp["out"], np.array([0.01, 0.0], np.float32)))
+    xb = torch.trunc(torch.sign(torch.randn((nb, cfgb.n_input), device=dev, generator=g))
+                     + 0.8 * torch.randn((nb, cfgb.n_input), device=dev, generator=g)).contiguous()
+    bank = BitwiseBank(models, device=dev, precision="f32")
+    flop_row = 2 * cfgb.n_input * cfgb.n_hidden_1 * P + 2 * cfgb.n_hidden_1 * 2 * P
+    resb = {}
+    for name, env in (("rows_resident_first_layers_streamed_K4c", None), ("lds_tiled_gemm_K4b", "0")):
+        if env is None:
+            os.environ.pop("NNV_BANK_STREAM", None)
+        else:
+            os.environ["NNV_BANK_STREAM"] = env
+        try:
+            rb = bank.decode(xb)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(2):
+                rb = bank.decode(xb)
+            e1.record()
+            torch.cuda.synchronize(dev)
+        finally:
+            os.environ.pop("NNV_BANK_STREAM", None)
+        ms = e0.elapsed_time(e1) / 2
+        resb[name] = {"value": nb * P / (ms * 1e-3), "unit": "decided bits/s", "ms_per_step": ms,
+                      "roofline_frac_of_fp32_mfma_peak": flop_row * nb / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f32"],
+                      "ones_decided": int(rb["bits"].sum(dtype=torch.int64).item())}
+    bank.close()
+    resb["decided_bits_identical"] = len({v["ones_decided"] for v in resb.values()}) == 1
+    out["bitwise_bank"] = {"workload": f"{P} bit positions x {nb} rows, {cfgb.n_input}-{cfgb.n_hidden_1}-2 ReLU per position, "
+                                       f"exact fp32, untrained weights, one launch", **resb}
+    return out
 
 
 def _free_port() -> int:
