@@ -201,6 +201,8 @@ def other_baseline_configs(dev, steps: int, net_headline):
     dec = torch.zeros((2 * L, B4), device=dev)
     dec[0] = 1.0
     dec[1:L + 1] = torch.sign(torch.randn((L, B4), device=dev, generator=g))
+    torch.cuda.empty_cache()   # the generator's temporaries (3 x 20 GB) would stay cached, and each forward's 20 GB of logits
+    lstm.forward(enc, dec)     # could then cost a hipMalloc / hipFree round trip inside the timed loop (seen in tools/bench_rnn.py)
     lstm.forward(enc, dec)
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
