@@ -559,6 +559,9 @@ def test_band_network_is_streamed_at_1024_threads(cuda_device, precision):
     120 KB packed).  Both choices were measured: since every wave streams its own class tiles from L2
     (round 4) the stream variant at 1024 threads is the faster one, and every row over several rounds of the persistent
     workgroups agrees with the C oracle under the near-tie rule."""
+    import os
+    if any(os.environ.get(k) for k in ("NNV_BAND_RESIDENT_512", "NNV_THREADS", "NNV_STREAM_MAX_RESIDENT")):
+        pytest.skip("an A/B switch forces another launch configuration (this test asserts the default one)")
     dims, b = [18, 128, 64, 32, 512], 9
     Ws, bs = _net(dims, seed=50)
     n = 300_077
