@@ -323,11 +323,20 @@ def _free_port() -> int:
 K1_SOURCES = ("nnv_mlp_decode.hip", "nnv_mlp_launch.hip", "nnv_internal.h")
 
 
+K1_HEADER_END = b"// nnv_dense.hip: layer-at-a-time path for wide networks"   # nnv_internal.h: K1's part ends here
+
+
 def k1_source_hash() -> str:
+    """SHA-1 over K1's kernel and launch sources and K1's part of the shared header (the other kernels' parameter
+    structs follow the marker; an edit there must not invalidate K1's profile -- it did in round 4).
+    tools/summarize_pmc.py computes the same value when it writes profiles/pmc_traffic.json."""
     h = hashlib.sha1()
     for name in K1_SOURCES:
         with open(os.path.join(ROOT, "neural-network-based-viterbi-decoding_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+            data = f.read()
+        if name == "nnv_internal.h" and K1_HEADER_END in data:
+            data = data[:data.index(K1_HEADER_END)]
+        h.update(data)
     return h.hexdigest()
 
 

@@ -139,7 +139,11 @@ if "f32" in k and "hbm_bytes_per_launch" in k["f32"]:
     h = hashlib.sha1()   # bench.k1_source_hash(): the kernel sources these counters were taken on
     for name in ("nnv_mlp_decode.hip", "nnv_mlp_launch.hip", "nnv_internal.h"):
         with open(os.path.join(here, "neural-network-based-viterbi-decoding_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+            data = f.read()
+        marker = b"// nnv_dense.hip: layer-at-a-time path for wide networks"   # K1's part of the shared header ends here
+        if name == "nnv_internal.h" and marker in data:
+            data = data[:data.index(marker)]
+        h.update(data)
     with open(os.path.join(here, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump({"rows_per_launch": ROWS, "hbm_bytes_per_launch": k["f32"]["hbm_bytes_per_launch"],
                    "k1_source_sha1": h.hexdigest(),
