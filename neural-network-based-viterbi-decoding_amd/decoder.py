@@ -639,6 +639,12 @@ def _cached_pack(weights: List[torch.Tensor], biases: List[torch.Tensor], device
     key = (str(device), precision) + tuple(
         (st._cdata, t.storage_offset(), tuple(t.shape), tuple(t.stride()), str(t.dtype)) for st, t in zip(storages, tensors))
     versions = tuple(t._version for t in tensors)
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        # check (3) waits for the device, which a capturing stream forbids -- and a graph would replay the weights of
+        # capture time anyway: say so instead of failing inside torch.equal
+        raise RuntimeError("nnviterbi torch ops take raw weight tensors and verify their bytes on every call (a device "
+                           "wait): they cannot be captured into a HIP graph. Hold a decoder.PackedMLP / WideMLP and "
+                           "capture its decode() instead (pure kernel launches).")
     snapshot = _content_snapshot(tensors)
     e = _PACK_CACHE.get(key)
     if e is not None:
@@ -648,15 +654,19 @@ def _cached_pack(weights: List[torch.Tensor], biases: List[torch.Tensor], device
         _evict(key)                                   # same storages, written in place since
     while len(_PACK_CACHE) >= _PACK_CACHE_MAX:
         _evict(next(iter(_PACK_CACHE)))               # least recently used
-    try:
-        net = PackedMLP(weights, biases, device=device, precision=precision)
-    except NNViterbiError as e:
-        # hidden widths the register-chained kernel has no instantiation for (they are free parameters of the
-        # reference's DecoderConfig): the same ops run through the wide path -- one persistent launch for the whole
-        # chain up to 512-wide layers (K6), one launch per layer beyond -- still on the GPU, same tolerances
-        if "unsupported network shape" not in str(e):
-            raise
-        net = WideMLP(weights, biases, device=device, precision=precision if len(biases[-1]) <= 32 else "f32")
+    wide_precision = precision if len(biases[-1]) <= 32 else "f32"
+    if len(weights) > _cabi.NNV_MAX_LAYERS:               # deeper than K1 chains layers: the wide path (up to 8)
+        net = WideMLP(weights, biases, device=device, precision=wide_precision)
+    else:
+        try:
+            net = PackedMLP(weights, biases, device=device, precision=precision)
+        except NNViterbiError as e:
+            # hidden widths the register-chained kernel has no instantiation for (they are free parameters of the
+            # reference's DecoderConfig): the same ops run through the wide path -- one persistent launch for the
+            # whole chain up to 512-wide layers (K6), one launch per layer beyond -- still on the GPU, same tolerances
+            if "unsupported network shape" not in str(e):
+                raise
+            net = WideMLP(weights, biases, device=device, precision=wide_precision)
     _PACK_CACHE[key] = _PackEntry(net, [StorageWeakRef(st) for st in storages], versions, snapshot)
     return net
 
@@ -698,8 +708,8 @@ def _forward_torch(x: torch.Tensor, weights: List[torch.Tensor], biases: List[to
 def _check_op_args(x, weights, biases, tile_bits=None, labels=None):
     if x.dtype != torch.float32 or x.dim() != 2:
         raise ValueError("x must be float32 [N, n_in]")
-    if len(weights) != len(biases) or not (2 <= len(weights) <= _cabi.NNV_MAX_LAYERS):
-        raise ValueError("need 2..4 dense layers with one bias vector each")
+    if len(weights) != len(biases) or not (2 <= len(weights) <= _cabi.NNV_WIDE_MAX_LAYERS):
+        raise ValueError("need 2..8 dense layers with one bias vector each")
     n_prev = x.shape[1]
     for W, b in zip(weights, biases):
         if W.dim() != 2 or W.shape[0] != n_prev or b.dim() != 1 or b.shape[0] != W.shape[1] \
@@ -752,6 +762,7 @@ def _(x, weights, biases, tile_bits, labels=None):
 def mlp_forward(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.Tensor]) -> torch.Tensor:
     """multilayer_perceptron(x, weights, biases) (src/fnn_viterbi.py:471-510): the tanh'd class layer
     [N, n_classes] float32 - debug / parity op."""
+    _check_op_args(x, weights, biases)
     net = _cached_pack(list(weights), list(biases), x.device)
     if isinstance(net, PackedMLP):
         return net.forward(x)

@@ -55,6 +55,14 @@ def test_cpu_key_edge_cases():
         torch.ops.nnviterbi.mlp_decode(torch.ones(3, 4), W, b, 1)          # 2**1 < 4 classes
     with pytest.raises(Exception):
         torch.ops.nnviterbi.mlp_decode(torch.ones(3, 4), W, b, 2, torch.zeros(3, dtype=torch.int64))
+    with pytest.raises(Exception):
+        torch.ops.nnviterbi.mlp_forward(torch.ones(3, 5), W, b)            # n_in mismatch, forward op too
+    # up to 8 dense layers (the wide path's depth); 9 are refused
+    deep_W = _t([np.eye(4, dtype=np.float32)] * 8)
+    deep_b = _t([np.zeros(4, np.float32)] * 7 + [np.array([0., 1., 0., 0.], np.float32)])
+    assert torch.ops.nnviterbi.mlp_decode(torch.zeros(2, 4), deep_W, deep_b, 2)[0].tolist() == [1, 1]
+    with pytest.raises(Exception):
+        torch.ops.nnviterbi.mlp_decode(torch.zeros(2, 4), deep_W + deep_W[:1], deep_b + deep_b[:1], 2)
 
 
 def test_product_never_imports_the_oracle():
@@ -276,11 +284,14 @@ def test_optimizer_step_behind_the_data_idiom_is_decoded_with_the_new_weights(cu
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dims,b", [([14, 200, 96, 48, 128], 7), ([16, 256, 128, 64, 256], 8), ([20, 300, 1024], 10)])
+@pytest.mark.parametrize("dims,b", [([14, 200, 96, 48, 128], 7), ([16, 256, 128, 64, 256], 8), ([20, 300, 1024], 10),
+                                    ([40, 100, 100, 100, 100, 2], 1), ([24, 64, 48, 48, 40, 32, 64], 6)])
 def test_op_takes_networks_of_other_hidden_widths(cuda_device, dims, b):
     """The reference's n_hidden_* are free parameters: shapes the register-chained kernel has no instantiation for must
     not make the OP fail -- it runs them through the wide path (one persistent launch for the whole chain up to
-    512-wide layers, one launch per layer beyond), same schema, same contract, cache included."""
+    512-wide layers, one launch per layer beyond), same schema, same contract, cache included.  The last two are DEEPER
+    than the register-chained kernel goes (5 and 6 dense layers: the sliding-window decoder's depth,
+    src/fnn_viterbi_seq_predict.py:343-414)."""
     rng = np.random.RandomState(len(dims) + b)
     Ws = [(rng.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
     bs = [(rng.randn(d) * 0.1).astype(np.float32) for d in dims[1:]]
@@ -298,4 +309,35 @@ def test_op_takes_networks_of_other_hidden_widths(cuda_device, dims, b):
     assert not bad.any() or O.top2_margin(o64)[bad].max() < TOL
     assert np.array_equal(g_bits.cpu().numpy(), O.class_to_bits(cls, b))
     assert np.array_equal(g_cnt.cpu().numpy(), O.error_counters(cls, labels, b))
+    decoder.clear_pack_cache()
+
+
+@pytest.mark.gpu
+@pytest.mark.filterwarnings("ignore:The CUDA Graph is empty")
+def test_op_under_graph_capture_says_what_to_do_instead(cuda_device):
+    """The ops verify the weights' bytes on every call (a device wait): inside a capture they must say so, not fail in
+    the middle of torch.equal -- and the handle's decode() must be what the message promises, capturable."""
+    rng = np.random.RandomState(5)
+    dims = [14, 128, 64, 32, 128]
+    Ws = _t([(rng.randn(dims[i], dims[i + 1]) * 0.3).astype(np.float32) for i in range(4)], "cuda")
+    bs = _t([(rng.randn(d) * 0.1).astype(np.float32) for d in dims[1:]], "cuda")
+    x = torch.from_numpy(rng.randn(512, 14).astype(np.float32)).cuda()
+    eager = torch.ops.nnviterbi.mlp_decode(x, Ws, bs, 7)[0].clone()
+    net = decoder.PackedMLP(Ws, bs, device="cuda")
+    net.decode(x, want_cls64=True)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match="cannot be captured"):
+            with torch.cuda.graph(g, stream=side):
+                torch.ops.nnviterbi.mlp_decode(x, Ws, bs, 7)
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        out = net.decode(x, want_cls64=True)["cls64"]
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    net.close()
     decoder.clear_pack_cache()
