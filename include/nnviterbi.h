@@ -287,10 +287,14 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev,
  * (32 columns per position) and finishes each position's 2-logit head in the
  * GEMM epilogue: one launch, every row read once per 4 positions' tile, the
  * hidden activations never leave the chip.
- * Since round 4 the fp32 bank of >= 2 positions runs with 32 received rows
- * resident in LDS and every position's first layer streamed from L2 into the
- * MFMA A operand (same results bit for bit; NNV_BANK_STREAM=0 in the
- * environment, read per call, keeps the tiled GEMM).
+ * Since round 4 the fp32 bank picks its kernel by size: >= 33 positions run
+ * with 32 received rows resident in LDS and every position's first layer
+ * streamed from L2 into the MFMA A operand (same results as the tiled GEMM bit
+ * for bit; NNV_BANK_STREAM=0 in the environment, read per call, keeps the
+ * tiled GEMM); 1-2 positions (the reference's own call shape is ONE per run)
+ * with 16-byte aligned rows run one HBM-streaming launch per position, the
+ * contraction split over the waves (same tolerances, another summation order;
+ * NNV_BANK_SINGLE=0 keeps the tiled GEMM).
  * ------------------------------------------------------------------------ */
 typedef struct nnv_bitwise_desc {
   int32_t n_input;        /* 2 (constraint_length + block_length); even           */

@@ -27,11 +27,21 @@ struct nnv_bitwise_handle {
                    // f16x3: W_hi [mpad][kpad] f16 | W_lo [mpad][kpad] f16 (together the bytes of the fp32 matrix) | bias | ...
   int64_t off_bias, off_hw, off_hb;
   // K4c (nnv_bitwise_stream.hip): rows resident in LDS, first layers streamed from L2 -- the fp32 bank's default
-  int32_t stream_ok;   // 1: stream_dev holds the fragment-order packing of the first layers
+  int32_t stream_ok;   // 1: stream_dev holds the fragment-order packing of the first layers, K4c may run
+  int32_t single_ok;   // 1: ... and K4d may run (one launch per position; the default for small banks)
   int32_t num_cus;
   int32_t groups;      // ceil(n_input / 8)
   float *stream_dev;   // [pos][group][lane][4]
 };
+
+namespace {
+// Banks of up to this many positions run as one K4d launch per position.  300 k rows of 1036 inputs, same box: one
+// position 0.254 ms (K4b, 32-column tile: 0.263), two 0.51 (K4b's 4-position column tile: 0.69), three 0.76 (0.68).
+constexpr int kSingleMaxPositions = 2;
+// K4c from this many positions on: below, a wave per position leaves waves idle and quantises the run to
+// ceil(P / 16) rounds (measured: P = 32 4.96 vs 4.92 ms for K4b, 48: 6.96 vs 7.31, 64: 8.96 vs 9.77).
+constexpr int kStreamMinPositions = 33;
+}  // namespace
 
 extern "C" {
 
@@ -112,8 +122,10 @@ int32_t nnv_bitwise_prepack_ex(const nnv_bitwise_desc *d, int32_t precision, nnv
   h->num_cus = prop.multiProcessorCount;
   h->groups = static_cast<int32_t>((K + 7) / 8);
   const int64_t frag_floats = P * h->groups * 256;
-  if (precision == NNV_PRECISION_F32 && P >= 2 && nnv::bank_stream_lds_bytes(h->groups) <= 160 * 1024 &&
-      frag_floats * 4 < (1LL << 31)) {
+  h->single_ok = 0;
+  const bool k4c = P >= 2 && nnv::bank_stream_lds_bytes(h->groups) <= 160 * 1024;
+  const bool k4d = P <= kSingleMaxPositions && nnv::bank_single_eligible(h->groups, K);
+  if (precision == NNV_PRECISION_F32 && (k4c || k4d) && frag_floats * 4 < (1LL << 31)) {
     std::vector<float> frag(static_cast<size_t>(frag_floats), 0.f);
     for (int64_t pos = 0; pos < P; ++pos) {
       const float *W1 = d->W1_host + pos * K * H;
@@ -127,10 +139,11 @@ int32_t nnv_bitwise_prepack_ex(const nnv_bitwise_desc *d, int32_t precision, nnv
       }
     }
     if (hipMalloc(reinterpret_cast<void **>(&h->stream_dev), frag.size() * sizeof(float)) == hipSuccess) {
-      if (hipMemcpy(h->stream_dev, frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
-          nnv::bank_stream_prepare(h->groups, dev) == NNV_OK) {
-        h->stream_ok = 1;
-      } else {
+      if (hipMemcpy(h->stream_dev, frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess) {
+        h->stream_ok = (k4c && nnv::bank_stream_prepare(h->groups, dev) == NNV_OK) ? 1 : 0;
+        h->single_ok = (k4d && nnv::bank_single_prepare(h->groups, dev) == NNV_OK) ? 1 : 0;
+      }
+      if (!h->stream_ok && !h->single_ok) {
         (void)hipFree(h->stream_dev);
         h->stream_dev = nullptr;
       }
@@ -160,31 +173,51 @@ int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, 
     const nnv_status dv = nnv::check_current_device(h->device);
     if (dv != NNV_OK) return dv;
   }
-  // K4c: rows resident in LDS, first layers streamed (fp32 banks of >= 2 positions).  NNV_BANK_STREAM=0, read per
-  // call, keeps the LDS-tiled GEMM (K4b) for A/B runs and for the tests that hold the two against each other.
-  if (h->stream_ok) {
-    const char *e = getenv("NNV_BANK_STREAM");
-    if (!(e && e[0] == '0')) {
-      nnv::BankStreamParams q{};
-      q.x = x_dev;
-      q.row_stride = h->n_input;
-      q.n_rows = n_rows;
-      q.n_blocks = (n_rows + 31) / 32;
-      q.x16 = (h->n_input % 4 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 16 == 0) ? 1 : 0;
-      q.K = h->n_input;
-      q.groups = h->groups;
-      q.n_pos = h->n_pos;
-      q.w_bytes = static_cast<int32_t>(static_cast<int64_t>(h->n_pos) * h->groups * 1024);
-      q.w = h->stream_dev;
-      q.bias = h->dev + h->off_bias;
-      q.head_w = h->dev + h->off_hw;
-      q.head_b = h->dev + h->off_hb;
-      q.bits = bits_dev;
-      q.head_act = act_dev;
-      q.labels = labels_dev;
-      q.errors = reinterpret_cast<unsigned long long *>(errors_dev);
-      return nnv::bank_stream_launch(q, h->num_cus, h->device, static_cast<hipStream_t>(stream));
+  // Which kernel (fp32): small banks one K4d launch per position (rows straight from HBM, the contraction split over the
+  // waves); large banks K4c (rows resident in LDS, first layers streamed); in between, and for anything neither takes,
+  // the LDS-tiled GEMM K4b.  NNV_BANK_STREAM=0 / NNV_BANK_SINGLE=0, read per call, switch K4c / K4d off for A/B runs
+  // and for the tests that hold the paths against each other; NNV_BANK_STREAM_MIN overrides K4c's lower bound.
+  const bool x16 = h->n_input % 4 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 16 == 0;
+  const auto off = [](const char *name) { const char *e = getenv(name); return e && e[0] == '0'; };
+  const bool use_single = h->single_ok && x16 && !off("NNV_BANK_SINGLE");
+  const char *min_env = getenv("NNV_BANK_STREAM_MIN");
+  const int stream_min = min_env ? atoi(min_env) : kStreamMinPositions;
+  const bool use_stream = !use_single && h->stream_ok && h->n_pos >= stream_min && !off("NNV_BANK_STREAM");
+  if (use_single || use_stream) {
+    nnv::BankStreamParams q{};
+    q.x = x_dev;
+    q.row_stride = h->n_input;
+    q.n_rows = n_rows;
+    q.n_blocks = (n_rows + 31) / 32;
+    q.x16 = x16 ? 1 : 0;
+    q.K = h->n_input;
+    q.groups = h->groups;
+    q.n_pos = h->n_pos;
+    q.w_bytes = static_cast<int32_t>(static_cast<int64_t>(h->n_pos) * h->groups * 1024);
+    q.w = h->stream_dev;
+    q.bias = h->dev + h->off_bias;
+    q.head_w = h->dev + h->off_hw;
+    q.head_b = h->dev + h->off_hb;
+    q.bits = bits_dev;
+    q.head_act = act_dev;
+    q.labels = labels_dev;
+    q.errors = reinterpret_cast<unsigned long long *>(errors_dev);
+    if (use_stream) return nnv::bank_stream_launch(q, h->num_cus, h->device, static_cast<hipStream_t>(stream));
+    q.n_pos = 1;
+    q.w_bytes = h->groups * 1024;
+    for (int64_t pos = 0; pos < h->n_pos; ++pos) {   // one launch per position, stream-ordered
+      const nnv_status e = nnv::bank_single_launch(q, h->num_cus, h->device, static_cast<hipStream_t>(stream));
+      if (e != NNV_OK) return e;
+      q.w += static_cast<int64_t>(h->groups) * 256;
+      q.bias += 32;
+      q.head_w += 64;
+      q.head_b += 2;
+      q.bits += n_rows;
+      if (q.head_act) q.head_act += 2 * n_rows;
+      if (q.labels) q.labels += n_rows;
+      if (q.errors) q.errors += 1;
     }
+    return NNV_OK;
   }
   nnv::DenseParams p{};
   p.A = x_dev;

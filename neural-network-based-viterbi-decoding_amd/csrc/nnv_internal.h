@@ -340,6 +340,11 @@ struct BankStreamParams {
 int64_t bank_stream_lds_bytes(int groups);
 nnv_status bank_stream_prepare(int groups, int device);
 nnv_status bank_stream_launch(const BankStreamParams &p, int num_cus, int device, hipStream_t stream);
+// nnv_bitwise_single.hip (K4d): ONE position, the contraction split over the 16 waves, rows straight from HBM into the
+// B operand, first-layer slice in registers.  p describes that one position (every per-position pointer pre-offset).
+bool bank_single_eligible(int groups, int64_t row_stride);
+nnv_status bank_single_prepare(int groups, int device);
+nnv_status bank_single_launch(const BankStreamParams &p, int num_cus, int device, hipStream_t stream);
 
 // nnv_generator.hip
 nnv_status generate_launch(int32_t code, int32_t tile_bits, int64_t n_rows,

@@ -104,8 +104,8 @@ def test_bank_argument_validation(cuda_device):
 @pytest.mark.parametrize("block_length,n_pos,n_rows", [(512, 40, 1500), (24, 24, 777), (25, 17, 129), (40, 3, 1),
                                                        (100, 33, 4099)])
 def test_streamed_bank_equals_the_tiled_bank_bit_for_bit(cuda_device, monkeypatch, block_length, n_pos, n_rows):
-    """K4c (rows resident in LDS, every position's first layer streamed from L2; the fp32 bank's default since round 4)
-    against K4b (LDS-tiled GEMM, NNV_BANK_STREAM=0, read per call): the same k order in the first layer and the same
+    """K4c (rows resident in LDS, every position's first layer streamed from L2; the fp32 bank's default from 33
+    positions on since round 4) against K4b (LDS-tiled GEMM, NNV_BANK_STREAM=0, read per call): the same k order in the first layer and the same
     sequential 32-term head chain, so decided bits, ReLU'd outputs and error counters are IDENTICAL, not just close."""
     cfg = bw.BitwiseDecoderConfig(block_length=block_length, training_size=4, test_size=n_rows, test_snr_index=3)
     np.random.seed(3 * block_length + n_pos)
@@ -115,6 +115,8 @@ def test_streamed_bank_equals_the_tiled_bank_bit_for_bit(cuda_device, monkeypatc
     labels = torch.from_numpy(np.ascontiguousarray(np.resize(info.T, (n_pos, n_rows)).astype(np.uint8))).cuda()
     bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models], precision="f32")
     monkeypatch.delenv("NNV_BANK_STREAM", raising=False)
+    monkeypatch.setenv("NNV_BANK_STREAM_MIN", "2")     # K4c whatever the bank's size (default: from 33 positions on)
+    monkeypatch.setenv("NNV_BANK_SINGLE", "0")         # ... and no per-position launches for the smallest banks
     a = bank.decode(x, labels=labels, want_act=True)
     monkeypatch.setenv("NNV_BANK_STREAM", "0")
     b = bank.decode(x, labels=labels, want_act=True)
@@ -126,4 +128,72 @@ def test_streamed_bank_equals_the_tiled_bank_bit_for_bit(cuda_device, monkeypatc
         pad[2:] = x.reshape(-1)
         c = bank.decode(pad[2:].view_as(x), labels=labels, want_act=True)
         assert torch.equal(c["bits"], a["bits"]) and torch.equal(c["act"], a["act"])
+    bank.close()
+
+
+def _bank_inputs(block_length, n_pos, n_rows, seed):
+    cfg = bw.BitwiseDecoderConfig(block_length=block_length, training_size=4, test_size=n_rows, test_snr_index=3)
+    np.random.seed(seed)
+    info, enc = bw.generate_test_data(cfg)
+    models = _models(cfg, n_pos, seed=seed + 5)
+    labels = np.ascontiguousarray(np.resize(info.T, (n_pos, n_rows)).astype(np.uint8))
+    return cfg, enc.astype(np.float32), models, labels
+
+
+# block_length -> n_input = 2 (6 + L): 1036 = 129.5 fragment groups (9 / 8 per wave, the row ends INSIDE the last group),
+# 412 = 51.5 (4 / 3), 64 = 8 (1 / 0: half the waves own nothing), 144 = 18 (2 / 1), 1152 = 144 (9 / 9, the largest taken)
+@pytest.mark.parametrize("block_length,n_pos,n_rows", [(512, 1, 9001), (512, 2, 1500), (200, 1, 4099), (26, 2, 31),
+                                                       (66, 1, 257), (570, 1, 640), (512, 1, 1)])
+def test_single_position_kernel_against_the_oracle_and_the_tiled_path(cuda_device, monkeypatch, block_length, n_pos, n_rows):
+    """K4d (round 4; banks of up to 2 positions, 16-byte aligned rows): rows straight from HBM into the MFMA B operand,
+    the contraction split over the 16 waves, partial sums meeting in LDS.  Per position against float64 and the C
+    restatement; against K4b (NNV_BANK_SINGLE=0) the outputs agree to rounding -- the summation ORDER differs (16
+    slice sums instead of one chain), so not bit for bit -- and the decided bits wherever the float64 margin is not a tie;
+    counters are exact functions of the bits; a second launch returns the same bytes."""
+    cfg, x_np, models, labels_np = _bank_inputs(block_length, n_pos, n_rows, seed=11 * block_length + n_pos)
+    x = torch.from_numpy(x_np).cuda()
+    labels = torch.from_numpy(labels_np).cuda()
+    bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models], precision="f32")
+    monkeypatch.delenv("NNV_BANK_SINGLE", raising=False)
+    a = bank.decode(x, labels=labels, want_act=True)
+    a2 = bank.decode(x, labels=labels, want_act=True)
+    assert torch.equal(a["bits"], a2["bits"]) and torch.equal(a["act"], a2["act"]) and torch.equal(a["errors"], a2["errors"])
+    monkeypatch.setenv("NNV_BANK_SINGLE", "0")
+    t = bank.decode(x, labels=labels, want_act=True)
+    monkeypatch.delenv("NNV_BANK_SINGLE", raising=False)
+    bits, act = a["bits"].cpu().numpy(), a["act"].cpu().numpy()
+    t_bits, t_act = t["bits"].cpu().numpy(), t["act"].cpu().numpy()
+    assert not torch.equal(a["act"], t["act"]) or n_rows < 64 or block_length < 100, "K4d did not run (same bytes as K4b)"
+    assert np.abs(act - t_act).max() < 2e-5 * max(1.0, np.abs(t_act).max())
+    for p, (w, b) in enumerate(models):
+        _check_position(bits[p].astype(np.int64), act[p], x_np, w, b)
+        assert a["errors"][p].item() == int((bits[p] != labels_np[p]).sum())
+        differ = bits[p] != t_bits[p]
+        if differ.any():                                   # only where the two outputs are a rounding apart
+            Ws, bs = bw.active_layers(w, b)
+            o64 = O.decode(x_np[differ], Ws, bs, 1, np.float64, activation="relu")[2]
+            assert O.top2_margin(o64).max() < 1e-4
+    bank.close()
+
+
+def test_single_position_kernel_keeps_rows_apart(cuda_device):
+    """Non-finite soft values stay inside their row -- including across the row END: n_input = 1036 is 129.5 fragment
+    groups, so the last group's upper half is the NEXT row's first four values, which K4d must never multiply (not even
+    by a zero weight: 0 x NaN).  Clean rows decode to the same bytes with and without poisoned neighbours."""
+    cfg, x_np, models, _ = _bank_inputs(512, 1, 700, seed=77)
+    bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models], precision="f32")
+    clean = bank.decode(torch.from_numpy(x_np).cuda(), want_act=True)
+    dirty = x_np.copy()
+    poisoned = np.array([1, 2, 40, 333, 699])
+    dirty[poisoned] = np.nan
+    dirty[2, :4] = np.inf                                   # the four values behind row 1's end
+    dirty[40, 500] = -np.inf
+    r = bank.decode(torch.from_numpy(dirty).cuda(), want_act=True)
+    r2 = bank.decode(torch.from_numpy(dirty).cuda(), want_act=True)
+    keep = np.ones(700, bool)
+    keep[poisoned] = False
+    keep_t = torch.from_numpy(keep).cuda()
+    assert torch.equal(r["bits"][:, keep_t], clean["bits"][:, keep_t])
+    assert torch.equal(r["act"][:, keep_t], clean["act"][:, keep_t])
+    assert torch.equal(r["bits"], r2["bits"])               # the poisoned rows: unspecified but repeatable
     bank.close()

@@ -63,8 +63,10 @@ for p in range(P):
 bank = BitwiseBank(models)
 msP, rP = timed(lambda: bank.decode(x), max(2, args.steps // 4))        # K4c: rows resident in LDS, first layers streamed
 os.environ["NNV_BANK_STREAM"] = "0"                                      # K4b: the LDS-tiled GEMM (read per call)
+os.environ["NNV_BANK_SINGLE"] = "0"
 msPt, rPt = timed(lambda: bank.decode(x), max(2, args.steps // 4))
 del os.environ["NNV_BANK_STREAM"]
+del os.environ["NNV_BANK_SINGLE"]
 tiled_same = bool(torch.equal(rPt["bits"], rP["bits"]))
 bitsP = rP["bits"][:, :m].cpu().numpy()
 mismP = 0
@@ -99,7 +101,7 @@ print(json.dumps({
         "ms_for_all_positions_this_way": ms1 * P,
     },
     "single_fused": {
-        "what": "one bit position, first layer + head in ONE launch (BitwiseBank of 1)", "value": n / (ms1f * 1e-3),
+        "what": "one bit position, first layer + head in ONE launch (BitwiseBank of 1: K4d, k-split over the waves, rows straight from HBM)", "value": n / (ms1f * 1e-3),
         "unit": "rows/s", "ms_per_step": ms1f,
         "roofline": {"bound": "hbm", "achieved": (4 * cfg.n_input + 1) * n / (ms1f * 1e-3) / 1e9, "peak": 8000.0,
                      "unit": "GB/s", "frac": (4 * cfg.n_input + 1) * n / (ms1f * 1e-3) / 8.0e12},
