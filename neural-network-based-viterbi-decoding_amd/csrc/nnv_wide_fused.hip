@@ -385,10 +385,12 @@ nnv_status wide_fused_launch(const WideFusedParams &p, int act, int num_cus, int
     const nnv_status e = fused_lds_optin(act, p.waves, device, lds_bytes);   // a no-op after prepack
     if (e != NNV_OK) return e;
   }
-  // persistent: one 16-wave workgroup per CU, two 8-wave or four 4-wave ones; short inputs: one 64-row step per workgroup
-  const int64_t steps = (p.n_units + 1) / 2;
+  // persistent: one 16-wave workgroup per CU, two 8-wave or four 4-wave ones.  Short inputs: one 32-row unit (a half
+  // step) per workgroup while there are fewer units than resident workgroups -- a launch is then as long as ONE step
+  // of one workgroup, and the half step is the shorter one (200 -> 500 x 4 -> 2, <= 8 k rows: 200 -> 1xx us; the
+  // layer-at-a-time path took 138-154 us there and was the faster one before: profiles/r04/wide_rows_sweep.txt)
   const int64_t resident = static_cast<int64_t>(num_cus) * (16 / p.waves);
-  int64_t blocks = steps < resident ? steps : resident;
+  int64_t blocks = p.n_units < resident ? p.n_units : resident;
   if (blocks < 1) blocks = 1;
   const dim3 grid(static_cast<unsigned>(blocks)), block(64 * p.waves);
   hipLaunchKernelGGL(fused_fn(act, p.waves), grid, block, lds_bytes, stream, p);
