@@ -397,6 +397,21 @@ def _pmc_child(blocks_per_gpu: int) -> None:
     net.close()
 
 
+def _kill_group(child) -> None:
+    """End the process group `child` leads (started here with start_new_session=True): TERM, then KILL."""
+    import signal
+    for sig, wait_s in ((signal.SIGTERM, 10), (signal.SIGKILL, 10)):
+        try:
+            os.killpg(child.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            child.communicate(timeout=wait_s)
+            return
+        except subprocess.TimeoutExpired:
+            continue
+
+
 def live_traffic(blocks_per_gpu: int, timeout_s: float = 90.0):
     """(traffic, traffic_source) MEASURED for this run: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, then
     WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots") over a child `bench.py
@@ -421,13 +436,17 @@ def live_traffic(blocks_per_gpu: int, timeout_s: float = 90.0):
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--blocks-per-gpu", str(blocks_per_gpu)]
             env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCPROF", "ROCP_"))}
             env["TMPDIR"] = "/tmp"
+            # its own process group: rocprofv3 is a launcher, the GPU process is ITS child -- on a time-out the whole
+            # group started here goes (a profiled child left behind would run beside the timed region)
+            child = subprocess.Popen(cmd, cwd=work, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                     start_new_session=True)
             try:
-                r = subprocess.run(cmd, cwd=work, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                                   timeout=timeout_s)
+                _, err = child.communicate(timeout=timeout_s)
             except subprocess.TimeoutExpired:
+                _kill_group(child)
                 return None, f"live PMC pass {ctr} exceeded {timeout_s:g} s"
-            if r.returncode != 0:
-                return None, f"live PMC pass {ctr} exited {r.returncode}: {r.stderr.decode(errors='replace')[-200:]}"
+            if child.returncode != 0:
+                return None, f"live PMC pass {ctr} exited {child.returncode}: {err.decode(errors='replace')[-200:]}"
             vals = []
             for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
                 with open(path, newline="") as f:

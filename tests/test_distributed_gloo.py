@@ -250,6 +250,11 @@ assert "--" in a and a[a.index("--") + 2].endswith("bench.py") and "--pmc-child"
 mode = os.environ.get("FAKE_MODE", "ok")
 if mode == "fail":
     sys.stderr.write("no counters today"); sys.exit(7)
+if mode == "stuck":   # like the real launcher: the profiled program is a CHILD of rocprofv3; both hang
+    import subprocess, time
+    c = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(300)"])
+    open(os.environ["FAKE_PID_FILE"], "w").write(str(c.pid))
+    time.sleep(300)
 os.makedirs(os.path.join(out, "host", "1"), exist_ok=True)
 lean = "void nnv::mlp_decode_kernel<0, 2, 3, 4, 2, 1, 1024, false, 2>(nnv::DecodeParams)"
 other = "void nnv::mlp_decode_kernel<0, 2, 3, 4, 2, 1, 1024, false, 0>(nnv::DecodeParams)"
@@ -272,6 +277,24 @@ with open(os.path.join(out, "host", "1", "run_counter_collection.csv"), "w") as 
     monkeypatch.setenv("FAKE_MODE", "empty")
     t, src = bench.live_traffic(1000, timeout_s=60)
     assert t is None and "no counter rows" in src
+    # a stuck profiler: the time limit ends the pass AND the profiled grandchild (its whole process group) -- nothing of
+    # it may run beside the timed region
+    import time
+    pid_file = tmp_path / "grandchild.pid"
+    monkeypatch.setenv("FAKE_MODE", "stuck")
+    monkeypatch.setenv("FAKE_PID_FILE", str(pid_file))
+    t0 = time.time()
+    t, src = bench.live_traffic(1000, timeout_s=3)
+    assert t is None and "exceeded 3 s" in src and time.time() - t0 < 30
+    pid = int(pid_file.read_text())
+    for _ in range(50):
+        try:
+            os.kill(pid, 0)                    # still there?  (0 = probe only)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the profiled grandchild survived the time-out")
     monkeypatch.setenv("PATH", str(tmp_path / "nothing"))
     t, src = bench.live_traffic(1000)
     assert t is None and "not on PATH" in src
