@@ -309,6 +309,31 @@ def next_row_paths(dev, steps: int):
     resb["decided_bits_identical"] = len({v["ones_decided"] for v in resb.values()}) == 1
     out["bitwise_bank"] = {"workload": f"{P} bit positions x {nb} rows, {cfgb.n_input}-{cfgb.n_hidden_1}-2 ReLU per position, "
                                        f"exact fp32, untrained weights, one launch", **resb}
+    # ... and ONE position, the reference's own call shape (one trained network per run): HBM-shaped.  K4d = the
+    # contraction split over the 16 waves, rows straight from HBM into the MFMA operand (csrc/nnv_bitwise_single.hip).
+    one = BitwiseBank(models[:1], device=dev, precision="f32")
+    res1 = {}
+    for name, env in (("k_split_rows_from_hbm_K4d", None), ("lds_tiled_gemm_K4b", "0")):
+        if env is not None:
+            os.environ["NNV_BANK_SINGLE"] = env
+        try:
+            for _ in range(3):
+                r1 = one.decode(xb)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(20):
+                r1 = one.decode(xb)
+            e1.record()
+            torch.cuda.synchronize(dev)
+        finally:
+            os.environ.pop("NNV_BANK_SINGLE", None)
+        ms = e0.elapsed_time(e1) / 20
+        res1[name] = {"value": nb / (ms * 1e-3), "unit": "rows/s", "ms_per_step": ms,
+                      "roofline_frac_of_hbm_peak": (4 * cfgb.n_input + 1) * nb / (ms * 1e-3) / 8.0e12,
+                      "ones_decided": int(r1["bits"].sum(dtype=torch.int64).item())}
+    one.close()
+    out["bitwise_one_position"] = {"workload": f"1 bit position x {nb} rows, {cfgb.n_input}-{cfgb.n_hidden_1}-2 ReLU, exact fp32, "
+                                               f"untrained weights ({4 * cfgb.n_input + 1} algorithmic bytes per row)", **res1}
     return out
 
 

@@ -173,6 +173,12 @@ def test_single_position_kernel_against_the_oracle_and_the_tiled_path(cuda_devic
             Ws, bs = bw.active_layers(w, b)
             o64 = O.decode(x_np[differ], Ws, bs, 1, np.float64, activation="relu")[2]
             assert O.top2_margin(o64).max() < 1e-4
+    # rows that are only 8-byte aligned (a view two floats into an allocation) are not K4d's: the call must still be
+    # served -- by the tiled path, whose bytes are known
+    pad = torch.empty(x.numel() + 2, dtype=torch.float32, device="cuda")
+    pad[2:] = x.reshape(-1)
+    u = bank.decode(pad[2:].view_as(x), labels=labels, want_act=True)
+    assert torch.equal(u["bits"], t["bits"]) and torch.equal(u["act"], t["act"]) and torch.equal(u["errors"], t["errors"])
     bank.close()
 
 
