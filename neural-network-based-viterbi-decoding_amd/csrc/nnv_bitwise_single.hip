@@ -170,6 +170,9 @@ __device__ __forceinline__ void single_run(const BankStreamParams &p, float *lds
         if (lane == 0 && m) atomicAdd(p.errors, static_cast<unsigned long long>(__popcll(m)));
       }
     }
+    // (Tried: ONE barrier per tile -- tile t's partials reduced at the start of pass t + 1, under the other waves' MFMAs,
+    // its head behind pass t + 1's barrier: 0.270-0.276 vs 0.257-0.259 ms on the same box, profiles/r04/
+    // bank_single_probe.txt; the serial LDS round trip at the head of every wave's pass costs more than the barrier.)
     buf ^= 1;   // the next tile writes the other buffers: its partials cannot reach this tile's reduction, which ended
                 // behind the second barrier; this tile's hidden values are read by the head wave before IT passes the
                 // next tile's first barrier, and rewritten only two tiles later
