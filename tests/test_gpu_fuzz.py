@@ -134,6 +134,38 @@ def test_bitwise_bank_random_shapes(cuda_device, seed, precision):
 
 
 @pytest.mark.parametrize("seed", range(10 * SCALE))
+def test_bitwise_bank_kernel_choice_random_shapes(cuda_device, seed):
+    """The fp32 bank's other two kernels, which the shapes above seldom reach: K4d (1-2 positions, rows a multiple of 4
+    floats, up to 1152 inputs; row counts past one tile per workgroup) on even seeds, K4c (>= 33 positions) on odd ones."""
+    from nnviterbi_amd.decoder import BitwiseBank
+    rng = np.random.RandomState(4500 + seed)
+    if seed % 2 == 0:
+        K, P = int(4 * rng.randint(1, 289)), int(rng.randint(1, 3))
+        n = int(rng.choice([1, 31, 33, 1000, 8193, 20001]))
+    else:
+        K, P = int(2 * rng.randint(1, 200)), int(rng.randint(33, 70))
+        n = int(rng.choice([1, 63, 129, 1000, 9000]))
+    H = int(rng.randint(1, 33))
+    models = []
+    for _ in range(P):
+        Ws, bs = _net([K, H, 2], rng, bias_scale=0.3)
+        models.append((Ws[0], bs[0], Ws[1], bs[1]))
+    x = np.trunc(rng.randn(n, K) * 1.5).astype(np.float32)
+    labels = (rng.rand(P, n) > 0.5).astype(np.uint8)
+    bank = BitwiseBank(models, precision="f32")
+    r = bank.decode(torch.from_numpy(x).cuda(), labels=torch.from_numpy(labels).cuda(), want_act=True)
+    bits, act, err = r["bits"].cpu().numpy(), r["act"].cpu().numpy(), r["errors"].cpu().numpy()
+    for p_ in rng.permutation(P)[:6]:
+        W1, b1, Wo, bo = models[p_]
+        o64 = O.forward(x, [W1, Wo], [b1, bo], np.float64, activation="relu")
+        assert np.abs(act[p_] - o64).max() < 2e-5 * max(1.0, np.abs(o64).max())
+        bad = bits[p_] != O.argmax_first(o64)
+        assert not bad.any() or O.top2_margin(o64)[bad].max() < 1e-4
+        assert err[p_] == int((bits[p_] != labels[p_]).sum())
+    bank.close()
+
+
+@pytest.mark.parametrize("seed", range(10 * SCALE))
 def test_wide_decoder_random_shapes(cuda_device, seed):
     """K4: 2..6 layers of arbitrary widths, matrix rows or a strided stream, tanh or ReLU."""
     rng = np.random.RandomState(2000 + seed)
