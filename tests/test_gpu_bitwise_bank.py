@@ -203,3 +203,25 @@ def test_single_position_kernel_keeps_rows_apart(cuda_device):
     assert torch.equal(r["act"][:, keep_t], clean["act"][:, keep_t])
     assert torch.equal(r["bits"], r2["bits"])               # the poisoned rows: unspecified but repeatable
     bank.close()
+
+
+@pytest.mark.parametrize("n_pos", [1, 2, 9, 40])      # K4d, K4d x 2 launches, K4b, K4c
+def test_bank_decode_is_hip_graph_capturable(cuda_device, n_pos):
+    """Whatever kernel the bank's size selects, a decode is pure kernel launches on the caller's stream (every kernel
+    attribute was set at prepack): capturable into a HIP graph without a warm-up launch, replayable on new rows."""
+    cfg, x_np, models, _ = _bank_inputs(100, n_pos, 2100, seed=900 + n_pos)
+    bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models], precision="f32")
+    xs = [torch.from_numpy(x_np).cuda(), torch.from_numpy(np.ascontiguousarray(x_np[::-1])).cuda()]
+    x = xs[0].clone()
+    bits = torch.empty((n_pos, 2100), dtype=torch.uint8, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        st = bank._lib.nnv_bitwise_decode_f32(bank._handle, x.data_ptr(), 2100, bits.data_ptr(), None, None, None,
+                                              torch.cuda.current_stream().cuda_stream)
+        assert st == 0
+    for src in xs:
+        x.copy_(src)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(bits, bank.decode(src)["bits"])
+    bank.close()
