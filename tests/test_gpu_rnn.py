@@ -74,6 +74,30 @@ def test_long_recurrence(cuda_device, scale, precision):
     net.close()
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_is_hip_graph_capturable(cuda_device, precision):
+    """The recurrent forward is one stream-ordered launch (no allocation, no synchronisation, no attribute set at launch):
+    capturable into a HIP graph without a warm-up and replayable on new symbols."""
+    t, batch = 48, 300
+    net = Seq2SeqLSTM(_params(20, 5), precision=precision)
+    pairs = [tuple(torch.from_numpy(a).cuda() for a in _inputs(t, t, batch, 60 + k)) for k in range(2)]
+    enc, dec = pairs[0][0].clone(), pairs[0][1].clone()
+    logits = torch.empty((t, batch), dtype=torch.float32, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        st = net._lib.nnv_seq2seq_forward_f32(net._handle, enc.data_ptr(), dec.data_ptr(), t, t, batch,
+                                              logits.data_ptr(), None, None, t, None,
+                                              torch.cuda.current_stream().cuda_stream)
+        assert st == 0
+    for e, d in pairs:
+        enc.copy_(e)
+        dec.copy_(d)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(logits, net.forward(e, d)["logits"])
+    net.close()
+
+
 def test_bits_and_counters_are_exact_functions_of_the_logits(cuda_device):
     p = _params(20, 5)
     L, batch = 10, 77
