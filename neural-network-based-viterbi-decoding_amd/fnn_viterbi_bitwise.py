@@ -161,8 +161,9 @@ def build_network(x, config: BitwiseDecoderConfig, weights: Optional[Dict] = Non
 
 def _run(x, weights, biases, want_act=False, want_cls64=False):
     """One network on the rows of ``x``.  ``n_hidden_1 <= 32`` (the reference's 30): first layer and
-    2-logit head in ONE fused launch (``decoder.BitwiseBank`` of one position: 0.31 ms for the default
-    300 k x 1036 test set against 0.36 ms for the two launches of the layer-at-a-time path); wider
+    2-logit head in ONE fused launch (``decoder.BitwiseBank`` of one position -- since round 4 the HBM-streaming
+    kernel K4d, csrc/nnv_bitwise_single.hip: 0.25 ms for the default 300 k x 1036 test set against 0.36 ms for the
+    two launches of the layer-at-a-time path); wider
     first layers go through ``decoder.WideMLP(activation="relu")``."""
     import torch
     from .decoder import BitwiseBank, WideMLP
