@@ -316,7 +316,7 @@ nnv_status wide_fused_prepare(const WideFusedParams &p, int act, int device);
 nnv_status wide_fused_launch(const WideFusedParams &p, int act, int num_cus, int device, hipStream_t stream);
 
 // nnv_bitwise_stream.hip (K4c): the bit-wise bank with 32 received rows resident in LDS and every position's first
-// layer streamed from L2 into the MFMA A operand.  Eligible: fp32, >= 2 positions, n_hidden <= 32, LDS for one row tile
+// layer streamed from L2 into the MFMA A operand.  Eligible: fp32, >= 2 positions (taken from 33 on), n_hidden <= 32, LDS for one row tile
 // ((2 ceil(n_input / 8) + 2) KB) <= 160 KB, packed first layers < 2 GB.
 struct BankStreamParams {
   const float *x;          // [n_rows][row_stride]
