@@ -170,6 +170,9 @@ __device__ __forceinline__ void single_run(const BankStreamParams &p, float *lds
         if (lane == 0 && m) atomicAdd(p.errors, static_cast<unsigned long long>(__popcll(m)));
       }
     }
+    // (Tried: 8-wave workgroups with TWO tiles of rows in flight per wave (k-slices of 16-17 groups: 68 + 136 + 16 of 256
+    // VGPRs, 6 spilled): 0.259-0.262 vs 0.258-0.260 ms on the same box -- the depth of the window is not what the
+    // overlap of the two sides waits for; not kept.)
     // (Tried: ONE barrier per tile -- tile t's partials reduced at the start of pass t + 1, under the other waves' MFMAs,
     // its head behind pass t + 1's barrier: 0.270-0.276 vs 0.257-0.259 ms on the same box, profiles/r04/
     // bank_single_probe.txt; the serial LDS round trip at the head of every wave's pass costs more than the barrier.)
