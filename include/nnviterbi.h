@@ -64,7 +64,12 @@ typedef enum nnv_precision {
 /* Convolutional codes of the reference's generators. */
 typedef enum nnv_code {
   NNV_CODE_57 = 0,     /* encode_57,     src/fnn_viterbi.py:122-154 (quirks kept) */
-  NNV_CODE_133171 = 1  /* encode_133171, src/fnn_viterbi.py:157-217               */
+  NNV_CODE_133171 = 1, /* encode_133171, src/fnn_viterbi.py:157-217               */
+  /* OR'ed into either code for nnv_awgn_generate_f32: the info bits of a BLOCK (rows_per_block consecutive
+   * rows) are ONE stream, encoded from zero state at the block's first row and chopped into rows -- the
+   * reference's "random test set" (src/fnn_viterbi_mixed_snr.py:464-475: encode the whole random stream, then
+   * reshape to [size, 2b]).  Without it every row is encoded from zero state, like a class (:351-352).      */
+  NNV_CODE_CONTINUOUS = 0x100
 } nnv_code;
 
 /*
@@ -203,6 +208,11 @@ int32_t nnv_mlp_forward_f32(const nnv_mlp_handle *h, const float *x_dev,
  * class (src/fnn_viterbi.py:351-352), BPSK-mapped (0 -> -1, 1 -> +1,
  * src/fnn_viterbi.py:244-247) and sigma * N(0,1) is added
  * (src/fnn_viterbi.py:250-251).
+ *
+ * With NNV_CODE_CONTINUOUS in `code` the encoder state runs on from row to row
+ * inside a block (rows_per_block rows = one stream from zero state; the labels
+ * stay each row's own info bits, as the reference labels its random test set,
+ * src/fnn_viterbi_mixed_snr.py:468-475); tile_bits >= 6 then for either code.
  *
  *  sigma_host      n_sigma standard deviations; block i = r / rows_per_block
  *                  uses sigma_host[i % n_sigma] (config 4's mixed-SNR sweep;

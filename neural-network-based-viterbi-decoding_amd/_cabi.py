@@ -20,6 +20,7 @@ NNV_MAX_LAYERS = 4
 NNV_OK = 0
 NNV_CODE_57 = 0
 NNV_CODE_133171 = 1
+NNV_CODE_CONTINUOUS = 0x100
 NNV_PRECISION = {"f32": 0, "f16x3": 1, "f16": 2}   # "f16": PackedMLP only (NNV_PRECISION_F16, outside the parity contract)
 
 EXPORTED_SYMBOLS = (

@@ -396,13 +396,16 @@ int32_t nnv_awgn_generate_f32(int32_t code, int32_t tile_bits, int64_t n_rows, i
   if (!sigma_host || n_sigma < 1 || n_sigma > 16) return NNV_ERR_INVALID_ARGUMENT;
   // the reference encoders index bits[5] / bits[1] unconditionally
   // (src/fnn_viterbi.py:143,201): shorter blocks are an error there too
-  if (code == NNV_CODE_133171) {
+  const int32_t base_code = code & ~NNV_CODE_CONTINUOUS;
+  if (base_code == NNV_CODE_133171) {
     if (tile_bits < 6) return NNV_ERR_INVALID_ARGUMENT;
-  } else if (code == NNV_CODE_57) {
+  } else if (base_code == NNV_CODE_57) {
     if (tile_bits < 2) return NNV_ERR_INVALID_ARGUMENT;
   } else {
     return NNV_ERR_INVALID_ARGUMENT;
   }
+  // a continuous stream reaches back 6 (2) bits: they must all lie in the previous row
+  if ((code & NNV_CODE_CONTINUOUS) && tile_bits < 6) return NNV_ERR_INVALID_ARGUMENT;
   if (tile_bits > 16) return NNV_ERR_INVALID_ARGUMENT;
   if (n_rows == 0) return NNV_OK;
   if (!x_dev) return NNV_ERR_INVALID_ARGUMENT;

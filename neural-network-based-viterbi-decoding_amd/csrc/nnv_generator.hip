@@ -69,9 +69,21 @@ __global__ __launch_bounds__(256) void awgn_generate_kernel(const GenParams p) {
     philox4x32_10(r_lo, r_hi, 0u, 0u, p.seed_lo, p.seed_hi, rnd);
     const int b = TB > 0 ? TB : p.tile_bits;
     const uint32_t cls = rnd[0] & ((1u << b) - 1u);  // MSB-first value of the info bits
-    // u(t) = info bit t (t = 0 is the first bit in time = the MSB of cls)
-    auto u = [&](int t) -> uint32_t { return t < 0 ? 0u : (cls >> (b - 1 - t)) & 1u; };
     const int64_t blk = static_cast<int64_t>(r / static_cast<uint64_t>(p.rows_per_block));
+    // Continuous mode (src/fnn_viterbi_mixed_snr.py:464-475: one stream per block, chopped into rows): the encoder
+    // memory at the start of this row is the END of the previous row of the same block -- that row's info bits are
+    // regenerated from its own counter, never read, so a row still depends on (seed, global row index) only.
+    uint32_t prev = 0u;       // bit k = info bit at time -(k + 1)
+    const bool first_of_block = r % static_cast<uint64_t>(p.rows_per_block) == 0;
+    if ((p.code & NNV_CODE_CONTINUOUS) && !first_of_block) {
+      const uint64_t rp = r - 1;
+      uint32_t q[4];
+      philox4x32_10(static_cast<uint32_t>(rp), static_cast<uint32_t>(rp >> 32), 0u, 0u, p.seed_lo, p.seed_hi, q);
+      prev = q[0] & ((1u << b) - 1u);   // its last bit in time is the LSB
+    }
+    const int base_code = p.code & ~NNV_CODE_CONTINUOUS;
+    // u(t) = info bit t (t = 0 is the first bit in time = the MSB of cls; t < 0 reaches into the previous row)
+    auto u = [&](int t) -> uint32_t { return t < 0 ? (prev >> (-t - 1)) & 1u : (cls >> (b - 1 - t)) & 1u; };
     const float sigma = p.sigma[blk % p.n_sigma];
     float *px = p.x + i * (2 * b);
     float row[TB > 0 ? 2 * TB + 2 : 4];   // TB > 0: the whole row (+2: odd TB draws a spare pair)
@@ -86,7 +98,7 @@ __global__ __launch_bounds__(256) void awgn_generate_kernel(const GenParams p) {
         const int t = t0 + d;
         if (t >= b) break;
         uint32_t e0, e1;
-        if (p.code == NNV_CODE_133171) {
+        if (base_code == NNV_CODE_133171) {
           // src/fnn_viterbi.py:207-215: taps 133 -> {0,2,3,5,6}, 171 -> {0,1,2,3,6}
           e0 = u(t) ^ u(t - 2) ^ u(t - 3) ^ u(t - 5) ^ u(t - 6);
           e1 = u(t) ^ u(t - 1) ^ u(t - 2) ^ u(t - 3) ^ u(t - 6);
@@ -94,7 +106,8 @@ __global__ __launch_bounds__(256) void awgn_generate_kernel(const GenParams p) {
           // src/fnn_viterbi.py:142-152: even = u[t]+u[t-2], odd = u[t]+u[t-1]+u[t-2],
           // except output index 1 which is u[0]+u[1] (:143)
           e0 = u(t) ^ u(t - 2);
-          e1 = (t == 0) ? (u(0) ^ u(1)) : (u(t) ^ u(t - 1) ^ u(t - 2));
+          // (the quirk belongs to output index 1 of the STREAM: in continuous mode only a block's first row has it)
+          e1 = (t == 0 && (first_of_block || !(p.code & NNV_CODE_CONTINUOUS))) ? (u(0) ^ u(1)) : (u(t) ^ u(t - 1) ^ u(t - 2));
         }
         const float v0 = (e0 ? 1.0f : -1.0f) + sigma * nz[2 * d];
         const float v1 = (e1 ? 1.0f : -1.0f) + sigma * nz[2 * d + 1];

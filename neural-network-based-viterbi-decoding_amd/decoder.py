@@ -544,16 +544,20 @@ class Seq2SeqLSTM:
 
 def generate_awgn_blocks(code: str, tile_bits: int, n_rows: int, sigma, seed: int,
                          first_row: int = 0, rows_per_block: int = 1, device=None,
-                         want_labels: bool = True):
+                         want_labels: bool = True, continuous: bool = False):
     """On-device synthetic received blocks (C ABI ``nnv_awgn_generate_f32``).
 
     Returns ``(x [n_rows, 2*tile_bits] float32, labels [n_rows] int32 | None)``.
-    ``sigma`` is a float or a sequence (block i uses sigma[i % len])."""
+    ``sigma`` is a float or a sequence (block i uses sigma[i % len]).  ``continuous``: a block's rows are one
+    stream encoded from zero state and chopped (the reference's "random test set",
+    src/fnn_viterbi_mixed_snr.py:464-475) instead of every row starting from zero state."""
     _require_cuda()
     lib = _cabi.load_library()
     dev = torch.device("cuda", torch.cuda.current_device() if device is None
                        else torch.device(device).index or 0)
     code_id = {"57": _cabi.NNV_CODE_57, "133171": _cabi.NNV_CODE_133171}[str(code)]
+    if continuous:
+        code_id |= _cabi.NNV_CODE_CONTINUOUS
     sig = np.atleast_1d(np.asarray(sigma, dtype=np.float32))
     x = torch.empty((n_rows, 2 * tile_bits), dtype=torch.float32, device=dev)
     labels = torch.empty(n_rows, dtype=torch.int32, device=dev) if want_labels else None

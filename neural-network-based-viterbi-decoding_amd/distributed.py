@@ -150,12 +150,15 @@ def rates(counters) -> Tuple[float, float]:
 
 def decode_blocks_sharded(net, code: str, tile_bits: int, n_blocks_total: int, rows_per_block: int,
                           sigmas, seed: int, rank: int = 0, world_size: int = 1,
-                          chunk_rows: int = 1 << 26, device=None) -> torch.Tensor:
+                          chunk_rows: int = 1 << 26, device=None, continuous: bool = False) -> torch.Tensor:
     """BASELINE config 4 driver: this rank's contiguous share of ``n_blocks_total`` synthetic
     blocks (block i at SNR bin i % len(sigmas)) is generated on the device and decoded chunk by
     chunk (at most ``chunk_rows`` rows resident at a time: 102 GB of input per GPU at full size
     would fit, but need not be resident).  Returns this rank's counters int64 [n_bins, 4];
-    combine ranks with :func:`all_reduce_counters`."""
+    combine ranks with :func:`all_reduce_counters`.  ``continuous``: every block is ONE stream encoded from zero
+    state and chopped into rows (the reference's "random test set", src/fnn_viterbi_mixed_snr.py:464-475) instead
+    of rows that each start from zero state -- chunk and shard boundaries change nothing (a row's encoder memory is
+    regenerated from the previous row's counter)."""
     from .decoder import generate_awgn_blocks
     import numpy as np
     sig = np.atleast_1d(np.asarray(sigmas, dtype=np.float32))
@@ -169,7 +172,7 @@ def decode_blocks_sharded(net, code: str, tile_bits: int, n_blocks_total: int, r
     while done < n_rows:
         m = min(int(chunk_rows), n_rows - done)
         x, labels = generate_awgn_blocks(code, tile_bits, m, sig, seed, first_row=first_row + done,
-                                         rows_per_block=rows_per_block, device=dev)
+                                         rows_per_block=rows_per_block, device=dev, continuous=continuous)
         net.decode_binned(x, labels, n_bins, rows_per_block, first_row=first_row + done,
                           counters=counters, tile_bits=tile_bits)
         done += m

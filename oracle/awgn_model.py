@@ -11,6 +11,8 @@ is not reproduced on the device), so this model pins the generator's CONTRACT:
   Box-Muller on 24-bit uniforms: u1 = ((a>>8)+1) 2^-24, u2 = (b>>8) 2^-24,
      n0 = sqrt(-2 ln u1) cos(2 pi u2), n1 = sqrt(-2 ln u1) sin(2 pi u2)
   x = BPSK(encode(bits)) + sigma[block % n_sigma] * n,  block = r // rows_per_block
+  continuous mode: encode() runs over the concatenated info bits of the whole block (zero state at the
+     block's first row only); classes and noise are unchanged
 
 The integer part (Philox words, class, code bits) is bit-exact; the Gaussian
 part is evaluated here in float64 and compared with a tolerance.
@@ -62,8 +64,12 @@ def encode_rows(code: str, class_bits: np.ndarray) -> np.ndarray:
 
 
 def generate(code: str, b: int, n_rows: int, sigma, seed: int, first_row: int = 0,
-             rows_per_block: int = 1):
-    """Returns (x float64 [n_rows, 2b], labels int32 [n_rows])."""
+             rows_per_block: int = 1, continuous: bool = False):
+    """Returns (x float64 [n_rows, 2b], labels int32 [n_rows]).
+
+    ``continuous``: the info bits of a block (rows_per_block consecutive global rows) are ONE stream,
+    encoded from zero state by the restated reference encoder and chopped into rows
+    (src/fnn_viterbi_mixed_snr.py:464-475, the "random test set"); labels stay each row's own bits."""
     sigma = np.atleast_1d(np.asarray(sigma, dtype=np.float32)).astype(np.float64)
     r = np.arange(first_row, first_row + n_rows, dtype=np.uint64)
     r_lo = (r & _MASK).astype(np.uint32)
@@ -73,8 +79,20 @@ def generate(code: str, b: int, n_rows: int, sigma, seed: int, first_row: int = 
     cls = (w[0] & np.uint32((1 << b) - 1)).astype(np.int32)
     bits = O.class_to_bits(cls, b)
     # encode each distinct class once
-    table = encode_rows(code, O.generate_class_bits(b))
-    coded = table[cls]
+    if continuous:
+        enc = O.encode_133171 if code == "133171" else O.encode_57
+        coded = np.zeros((n_rows, 2 * b), dtype=np.int32)
+        first_blk, last_blk = first_row // rows_per_block, (first_row + n_rows - 1) // rows_per_block
+        for blk_i in range(first_blk, last_blk + 1):          # whole blocks, whatever part of them was asked for
+            rr = np.arange(blk_i * rows_per_block, (blk_i + 1) * rows_per_block, dtype=np.uint64)
+            wb = philox4x32_10((rr & _MASK).astype(np.uint32), (rr >> np.uint64(32)).astype(np.uint32), 0, 0, k0, k1)
+            stream = O.class_to_bits((wb[0] & np.uint32((1 << b) - 1)).astype(np.int32), b).reshape(-1)
+            rows = np.asarray(enc(stream)).reshape(rows_per_block, 2 * b)
+            lo, hi = max(first_row, int(rr[0])), min(first_row + n_rows, int(rr[-1]) + 1)
+            coded[lo - first_row:hi - first_row] = rows[lo - int(rr[0]):hi - int(rr[0])]
+    else:
+        table = encode_rows(code, O.generate_class_bits(b))
+        coded = table[cls]
     noise = np.zeros((n_rows, 2 * b), dtype=np.float64)
     for t in range((b + 1) // 2):
         g = philox4x32_10(r_lo, r_hi, t, 1, k0, k1)

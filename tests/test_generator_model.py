@@ -42,3 +42,26 @@ def test_signal_part_is_the_reference_codeword_and_noise_is_gaussian():
     x57, l57 = A.generate("57", 5, 64, 0.0, seed=3)
     want57 = np.stack([O.encode_57(r) for r in O.generate_class_bits(5)])[l57]
     assert np.array_equal(x57, np.where(want57 == 1, 1.0, -1.0))
+
+
+def test_continuous_mode_is_the_reference_random_test_set_shape():
+    """continuous=True: a block's info bits are ONE stream through the restated reference encoder, chopped into rows
+    (src/fnn_viterbi_mixed_snr.py:464-475); classes, labels and noise are those of the per-row mode; a block of one row
+    IS the per-row mode; rows do not depend on how the call range cuts the blocks."""
+    b, n, rpb = 8, 96, 12
+    x, lab = A.generate("133171", b, n, 0.0, seed=21, rows_per_block=rpb, continuous=True)
+    x_rows, lab_rows = A.generate("133171", b, n, 0.0, seed=21, rows_per_block=rpb)
+    assert np.array_equal(lab, lab_rows)
+    bits = O.class_to_bits(lab, b)
+    for blk in range(n // rpb):
+        stream = bits[blk * rpb:(blk + 1) * rpb].reshape(-1)
+        want = np.where(O.encode_133171(stream) == 1, 1.0, -1.0).reshape(rpb, 2 * b)
+        assert np.array_equal(x[blk * rpb:(blk + 1) * rpb], want)
+        assert np.array_equal(x[blk * rpb], x_rows[blk * rpb])            # a block's first row starts from zero state
+    assert not np.array_equal(x, x_rows)                                   # ... the others do not
+    one, _ = A.generate("57", 6, 40, 0.3, seed=4, rows_per_block=1, continuous=True)
+    one_rows, _ = A.generate("57", 6, 40, 0.3, seed=4, rows_per_block=1)
+    assert np.array_equal(one, one_rows)
+    xa, la = A.generate("57", 6, 17, 0.3, seed=4, first_row=5, rows_per_block=7, continuous=True)
+    xb, lb = A.generate("57", 6, 30, 0.3, seed=4, first_row=0, rows_per_block=7, continuous=True)
+    assert np.array_equal(xa, xb[5:22]) and np.array_equal(la, lb[5:22])

@@ -481,6 +481,28 @@ def test_generator_is_independent_of_sharding_and_rejects_short_tiles(cuda_devic
         generate_awgn_blocks("57", 1, 10, 0.5, 0)
 
 
+@pytest.mark.parametrize("code,b,rpb", [("133171", 8, 16), ("133171", 7, 5), ("133171", 6, 3), ("57", 10, 4),
+                                        ("57", 6, 1), ("133171", 8, 5000)])
+def test_generator_continuous_mode_matches_the_numpy_model(cuda_device, code, b, rpb):
+    """NNV_CODE_CONTINUOUS: a block's rows are one stream from zero state, chopped (the reference's "random test set",
+    src/fnn_viterbi_mixed_snr.py:464-475).  Bit exact against the model (which runs the restated reference encoder over
+    each block's concatenated bits), from a first row in the MIDDLE of a block, and independent of the sharding."""
+    n, seed, sig = 3000, 987654321, [0.5616748812614791, 0.7]
+    x, lab = generate_awgn_blocks(code, b, n, sig, seed, first_row=7, rows_per_block=rpb, continuous=True)
+    mx_, ml = awgn_model.generate(code, b, n, sig, seed, first_row=7, rows_per_block=rpb, continuous=True)
+    assert np.array_equal(lab.cpu().numpy(), ml)
+    assert np.abs(x.cpu().numpy() - mx_).max() < 1e-5
+    x0, _ = generate_awgn_blocks(code, b, n, 0.0, seed, first_row=7, rows_per_block=rpb, continuous=True)
+    m0, _ = awgn_model.generate(code, b, n, 0.0, seed, first_row=7, rows_per_block=rpb, continuous=True)
+    assert np.array_equal(x0.cpu().numpy(), m0)
+    xa, la = generate_awgn_blocks(code, b, 1234, sig, seed, first_row=7, rows_per_block=rpb, continuous=True)
+    xb, lb = generate_awgn_blocks(code, b, n - 1234, sig, seed, first_row=7 + 1234, rows_per_block=rpb, continuous=True)
+    assert torch.equal(torch.cat([xa, xb]), x) and torch.equal(torch.cat([la, lb]), lab)
+    if code == "57":
+        with pytest.raises(nnviterbi_amd.NNViterbiError):
+            generate_awgn_blocks("57", 5, 10, 0.5, 0, continuous=True)   # the stream reaches back into ONE previous row
+
+
 # ------------------------------------------------------------------ full size (BASELINE configs[2])
 def matched_filter_network(b, code, n_layers=3):
     """A hand-built network of the reference's architecture that decodes
@@ -678,6 +700,14 @@ def test_mixed_snr_sweep_per_bin_counters(cuda_device):
     parts = [nd.decode_blocks_sharded(net, "133171", b, n_blocks, rpb, sig, seed, rank=k, world_size=2,
                                       chunk_rows=1000) for k in range(2)]
     assert np.array_equal((parts[0] + parts[1]).cpu().numpy(), want)
+    # the same driver over CONTINUOUS blocks (one stream per block, the reference's "random test set" shape): one call
+    # == two ranks x ragged chunks; and a zero-state network does worse on them (rows start from an unknown state)
+    one = nd.decode_blocks_sharded(net, "133171", b, n_blocks, rpb, sig, seed, continuous=True)
+    parts = [nd.decode_blocks_sharded(net, "133171", b, n_blocks, rpb, sig, seed, rank=k, world_size=2,
+                                      chunk_rows=1000, continuous=True) for k in range(2)]
+    assert torch.equal(parts[0] + parts[1], one)
+    assert np.array_equal(one[:, 2:].cpu().numpy(), want[:, 2:])          # same totals
+    assert int(one[:, 0].sum()) > int(want[:, 0].sum())                  # more bit errors than on zero-state rows
     with pytest.raises(nnviterbi_amd.NNViterbiError):
         net.decode_binned(x, lab, 17, rpb)           # more than 16 bins
     net.close()
