@@ -172,7 +172,10 @@ __device__ __forceinline__ void single_run(const BankStreamParams &p, float *lds
     }
     // (Tried: 8-wave workgroups with TWO tiles of rows in flight per wave (k-slices of 16-17 groups: 68 + 136 + 16 of 256
     // VGPRs, 6 spilled): 0.259-0.262 vs 0.258-0.260 ms on the same box -- the depth of the window is not what the
-    // overlap of the two sides waits for; not kept.)
+    // overlap of the two sides waits for; not kept.  The same 8-wave kernel with the next tile's whole slice requested
+    // at the START of a pass, ahead of every MFMA (tools/ubench_hbm_mfma.hip: a SIMD busy with fp32 MFMA chains hardly
+    // issues anything for its other waves, so a refill behind a wave's MFMAs also waits for the other waves'):
+    // 0.279-0.281 vs 0.258-0.261 ms.)
     // (Tried: ONE barrier per tile -- tile t's partials reduced at the start of pass t + 1, under the other waves' MFMAs,
     // its head behind pass t + 1's barrier: 0.270-0.276 vs 0.257-0.259 ms on the same box, profiles/r04/
     // bank_single_probe.txt; the serial LDS round trip at the head of every wave's pass costs more than the barrier.)
