@@ -3,13 +3,15 @@
 // One persistent workgroup of 16 waves per CU: waves 0-7 stream a buffer from HBM (16-byte loads, fully coalesced, 8 loads
 // in flight per wave), waves 8-15 run dependent v_mfma_f32_32x32x2_f32 chains -- independent work, nothing shared.
 //   mode 0: the streaming waves alone; mode 1: the MFMA waves alone; mode 2: both.
+// Variants: a streaming loop WITHOUT any vector-ALU instruction (inline asm); the two kinds of waves on separate SIMDs;
+// 16-bit MFMA chains (v_mfma_f32_32x32x16_f16) instead of fp32 ones.
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench_hbm_mfma.hip -o tools/ubench_hbm_mfma
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-__global__ __launch_bounds__(1024) void k(const u32x4 *buf, size_t n_vec, int mfma_iters, int mode, unsigned *out, int novalu, int split) {
+__global__ __launch_bounds__(1024) void k(const u32x4 *buf, size_t n_vec, int mfma_iters, int mode, unsigned *out, int novalu, int split, int f16) {
   const int wave0 = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // split 0: waves 0-7 stream (two streaming + two MFMA waves on every SIMD: waves sit on SIMD wave % 4);
   // split 1: the waves of SIMDs 0 and 1 stream, those of SIMDs 2 and 3 run MFMAs (four of a kind per SIMD)
@@ -67,6 +69,15 @@ __global__ __launch_bounds__(1024) void k(const u32x4 *buf, size_t n_vec, int mf
     if (mode == 0) return;
     f32x16 a = {0};
     float x = 1.0f + lane * 1e-9f, y = 0.5f;
+    if (f16) {   // the same chains on the 16-bit matrix path (v_mfma_f32_32x32x16_f16: 8 passes, co-executes with the vector ALU)
+      using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+      f16x8 hx, hy;
+      for (int e = 0; e < 8; ++e) hx[e] = (_Float16)x, hy[e] = (_Float16)y;
+      for (int it = 0; it < mfma_iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(hx, hy, a, 0, 0, 0);
+      }
+    } else
     for (int it = 0; it < mfma_iters; ++it) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) a = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a, 0, 0, 0);
@@ -83,11 +94,11 @@ int main() {
   hipMalloc(&buf, bytes); hipMalloc(&out, 64);
   hipMemset(buf, 1, bytes);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  int novalu = 0, split = 0;
+  int novalu = 0, split = 0, f16 = 0;
   auto run = [&](int mode, int mfma_iters) {
-    hipLaunchKernelGGL(k, dim3(256), dim3(1024), 0, 0, buf, bytes / 16, mfma_iters, mode, out, novalu, split);
+    hipLaunchKernelGGL(k, dim3(256), dim3(1024), 0, 0, buf, bytes / 16, mfma_iters, mode, out, novalu, split, f16);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k, dim3(256), dim3(1024), 0, 0, buf, bytes / 16, mfma_iters, mode, out, novalu, split);
+    hipLaunchKernelGGL(k, dim3(256), dim3(1024), 0, 0, buf, bytes / 16, mfma_iters, mode, out, novalu, split, f16);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); return ms;
   };
@@ -97,9 +108,15 @@ int main() {
   int iters = 1000;
   float t_mfma = run(1, iters);
   iters = (int)(iters * t_load / t_mfma);
-  for (int rep = 0; rep < 8; ++rep) {
+  for (int rep = 0; rep < 12; ++rep) {
     novalu = (rep & 3) >= 2;
-    split = rep >= 4;
+    split = rep >= 4 && rep < 8;
+    f16 = rep >= 8;
+    if (rep == 8) {   // 16-bit chains, two of each kind per SIMD again: recalibrate
+      const float tl = run(0, 0), tm = run(1, 1000);
+      iters = (int)(1000 * tl / tm);
+    }
+    if (f16) printf("[16-bit MFMA chains] ");
     if (rep == 4) {   // four MFMA waves on two SIMDs: recalibrate the MFMA side to the streaming side
       const float tl = run(0, 0), tm = run(1, 1000);
       iters = (int)(1000 * tl / tm);
@@ -111,8 +128,8 @@ int main() {
     hipMemcpy(out + 2, init + 1, 24, hipMemcpyHostToDevice);
     const float c = run(2, iters);   // (two launches: the maxima are over both, the minimum start is the first launch's)
     hipMemcpy(got + 1, out + 2, 24, hipMemcpyDeviceToHost);
-    printf("streaming alone %.3f ms (%.2f TB/s) | MFMA alone %.3f ms (%.1f %% of the fp32 peak with 2 waves per SIMD) | both %.3f ms = %.2f x the slower side; in the second 'both' launch the last MFMA wave ended %.3f ms before the last streaming wave\n",
-           a, bytes / a / 1e9, b, 100.0 * (256.0 * 8 * iters * 16 * 4096) / (b * 1e-3) / 157.3e12, c, c / (a > b ? a : b), ((double)got[1] - (double)got[2]) / 1e5);
+    printf("streaming alone %.3f ms (%.2f TB/s) | MFMA alone %.3f ms (%.0f TFLOP/s) | both %.3f ms = %.2f x the slower side; in the second 'both' launch the last MFMA wave ended %.3f ms before the last streaming wave\n",
+           a, bytes / a / 1e9, b, (256.0 * 8 * iters * 16 * (f16 ? 32768.0 : 4096.0)) / (b * 1e-3) / 1e12, c, c / (a > b ? a : b), ((double)got[1] - (double)got[2]) / 1e5);
   }
   return 0;
 }
