@@ -11,7 +11,7 @@
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-__global__ __launch_bounds__(1024) void k(const u32x4 *buf, size_t n_vec, int mfma_iters, int mode, unsigned *out, int novalu, int split, int f16) {
+__global__ __launch_bounds__(1024) void k(const u32x4 *buf, size_t n_vec, int mfma_iters, int mode, unsigned *out, int novalu, int split, int f16, int prio) {
   const int wave0 = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // split 0: waves 0-7 stream (two streaming + two MFMA waves on every SIMD: waves sit on SIMD wave % 4);
   // split 1: the waves of SIMDs 0 and 1 stream, those of SIMDs 2 and 3 run MFMAs (four of a kind per SIMD)
@@ -19,6 +19,7 @@ __global__ __launch_bounds__(1024) void k(const u32x4 *buf, size_t n_vec, int mf
   const int wave = split ? ((wave0 >> 2) * 2 + (wave0 & 1)) : (wave0 & 7);   // 0..7 within its kind
   if (streams) {
     if (mode == 1) return;
+    if (prio) __builtin_amdgcn_s_setprio(3);   // does a higher issue priority get the streaming waves their turns?
     if (novalu) {
       // the same stream with NO vector-ALU instruction in the loop: scalar-addressed buffer loads whose results are
       // never read (inline asm), scalar loop counter -- the vector ALU port is what fp32 MFMAs do not share
@@ -94,11 +95,11 @@ int main() {
   hipMalloc(&buf, bytes); hipMalloc(&out, 64);
   hipMemset(buf, 1, bytes);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  int novalu = 0, split = 0, f16 = 0;
+  int novalu = 0, split = 0, f16 = 0, prio = 0;
   auto run = [&](int mode, int mfma_iters) {
-    hipLaunchKernelGGL(k, dim3(256), dim3(1024), 0, 0, buf, bytes / 16, mfma_iters, mode, out, novalu, split, f16);
+    hipLaunchKernelGGL(k, dim3(256), dim3(1024), 0, 0, buf, bytes / 16, mfma_iters, mode, out, novalu, split, f16, prio);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k, dim3(256), dim3(1024), 0, 0, buf, bytes / 16, mfma_iters, mode, out, novalu, split, f16);
+    hipLaunchKernelGGL(k, dim3(256), dim3(1024), 0, 0, buf, bytes / 16, mfma_iters, mode, out, novalu, split, f16, prio);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); return ms;
   };
@@ -108,10 +109,16 @@ int main() {
   int iters = 1000;
   float t_mfma = run(1, iters);
   iters = (int)(iters * t_load / t_mfma);
-  for (int rep = 0; rep < 12; ++rep) {
+  for (int rep = 0; rep < 16; ++rep) {
     novalu = (rep & 3) >= 2;
     split = rep >= 4 && rep < 8;
-    f16 = rep >= 8;
+    f16 = rep >= 8 && rep < 12;
+    prio = rep >= 12;
+    if (rep == 12) {  // fp32 chains, two of each kind per SIMD, the streaming waves at s_setprio 3: recalibrate
+      const float tl = run(0, 0), tm = run(1, 1000);
+      iters = (int)(1000 * tl / tm);
+    }
+    if (prio) printf("[streaming waves at s_setprio 3] ");
     if (rep == 8) {   // 16-bit chains, two of each kind per SIMD again: recalibrate
       const float tl = run(0, 0), tm = run(1, 1000);
       iters = (int)(1000 * tl / tm);
