@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NNV_ABI_VERSION 4 /* 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex */
+#define NNV_ABI_VERSION 5 /* 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS */
 #define NNV_MAX_LAYERS 4 /* dense layers incl. the output layer */
 
 typedef enum nnv_status {

@@ -15,7 +15,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("NNV_LIB") or os.path.join(_PKG_DIR, "libnnviterbi_hip.so")
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 
-NNV_ABI_VERSION = 4
+NNV_ABI_VERSION = 5
 NNV_MAX_LAYERS = 4
 NNV_OK = 0
 NNV_CODE_57 = 0

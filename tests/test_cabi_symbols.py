@@ -45,7 +45,7 @@ def test_header_cites_the_reference_for_each_compute_entry():
 
 
 def test_version_and_status_strings(lib):
-    assert lib.nnv_abi_version() == _cabi.NNV_ABI_VERSION == 4
+    assert lib.nnv_abi_version() == _cabi.NNV_ABI_VERSION == 5
     assert lib.nnv_status_string(0) == b"ok"
     assert b"unsupported" in lib.nnv_status_string(2)
     assert lib.nnv_device_count() >= 0
