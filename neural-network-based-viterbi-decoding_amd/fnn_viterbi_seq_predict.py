@@ -188,6 +188,43 @@ def predict_stream(coded_seq: np.ndarray, n_instances: int, weights: Dict, biase
         net.close()
 
 
+def generate_test_stream_on_device(n_info_bits: int, sigma: float, seed: int, device=None):
+    """The test stream of ``generate_test_data`` (:255-286) for LONG streams, made on the GPU: ``n_info_bits`` random
+    bits (rounded up to a multiple of 8) -> (133,171) from zero state as ONE stream -> BPSK + AWGN -> truncated toward
+    zero like the reference's int32 destination.  Returns ``(info uint8 [n] , coded float32 [2n])`` CUDA
+    tensors.  Philox-keyed by (seed, position): not the reference's numpy draws (a device generator cannot be), the
+    same contract as ``decoder.generate_awgn_blocks(..., continuous=True)``, whose rows ARE this stream."""
+    import torch
+    from .decoder import generate_awgn_blocks
+    rows = (int(n_info_bits) + 7) // 8
+    x, labels = generate_awgn_blocks("133171", 8, rows, float(sigma), int(seed), rows_per_block=rows,
+                                     device=device, continuous=True)
+    shifts = torch.arange(7, -1, -1, dtype=torch.int32, device=x.device)
+    info = ((labels[:, None] >> shifts[None, :]) & 1).to(torch.uint8).reshape(-1)
+    return info, torch.trunc(x.reshape(-1))
+
+
+def evaluate_stream_on_device(weights: Dict, biases: Dict, n_info_bits: int, sigma: float, seed: int,
+                              window_length: Optional[int] = None, device=None) -> Dict:
+    """Generate a test stream on the GPU and decode every full window of it (window i = coded[2i : 2i + window] decides
+    info bit i, :293-336) in one persistent launch; returns the error count and rate over the decodable bits."""
+    import torch
+    from .decoder import WideMLP
+    Ws, bs = weights_as_lists(weights, biases)
+    window = int(np.asarray(Ws[0]).shape[0]) if window_length is None else int(window_length)
+    info, coded = generate_test_stream_on_device(n_info_bits, sigma, seed, device=device)
+    n_instances = (coded.numel() - window) // 2 + 1
+    if n_instances < 1:
+        raise ValueError("the stream is shorter than one window")
+    net = WideMLP(Ws, bs, device=coded.device)
+    try:
+        pred = net.decode_stream(coded, n_instances)["cls32"]
+    finally:
+        net.close()
+    errors = int((pred != info[:n_instances].to(torch.int32)).sum().item())
+    return {"decoded_bits": n_instances, "bit_errors": errors, "ber": errors / n_instances}
+
+
 def _ckpt(path: str) -> str:
     return path if path.endswith(".npz") else path + ".npz"
 

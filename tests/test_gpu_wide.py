@@ -380,3 +380,32 @@ def test_fused_chain_is_hip_graph_capturable(cuda_device):
         torch.cuda.synchronize()
         assert torch.equal(cls, net.decode_stream(src, n)["cls32"])
     net.close()
+
+
+def test_sliding_window_stream_generated_and_decoded_on_the_device(cuda_device):
+    """fnn_viterbi_seq_predict.generate_test_stream_on_device / evaluate_stream_on_device: a long test stream (random bits
+    -> (133,171) as ONE stream from zero state -> BPSK + AWGN -> truncation toward zero, src/fnn_viterbi_seq_predict.py:
+    255-286 + F12) made by K3's continuous mode, every window decoded in one persistent launch.  The stream equals the
+    generator's numpy model run through the restated reference encoder; the error count equals the host pipeline's
+    (predict_stream on the downloaded stream)."""
+    from oracle import awgn_model
+    n_bits, sigma, seed = 4096, 0.5, 77
+    info, coded = sq.generate_test_stream_on_device(n_bits, sigma, seed)
+    rows = n_bits // 8
+    mx_, ml = awgn_model.generate("133171", 8, rows, sigma, seed, rows_per_block=rows, continuous=True)
+    assert np.array_equal(info.cpu().numpy(), O.class_to_bits(ml, 8).reshape(-1))
+    model_stream = np.trunc(mx_.reshape(-1))
+    got = coded.cpu().numpy()
+    # truncation is discontinuous at integers: a float32 value within 1e-5 of one may land on the other side
+    differ = got != model_stream
+    assert differ.mean() < 1e-3 and np.all(np.abs(mx_.reshape(-1)[differ] - np.round(mx_.reshape(-1)[differ])) < 1e-4)
+    cfg = sq.SequentialDecoderConfig()
+    w, b = sq.initialize_weights(cfg, rng=np.random.RandomState(3))
+    r = sq.evaluate_stream_on_device(w, b, n_bits, sigma, seed)
+    n_inst = (2 * n_bits - cfg.window_length) // 2 + 1
+    assert r["decoded_bits"] == n_inst
+    host_pred = sq.predict_stream(got[None, :], n_inst, w, b)
+    assert r["bit_errors"] == int((host_pred != info.cpu().numpy()[:n_inst]).sum())
+    assert 0.0 <= r["ber"] <= 1.0
+    with pytest.raises(ValueError):
+        sq.evaluate_stream_on_device(w, b, 64, sigma, seed)          # 128 symbols: shorter than one 200-symbol window
