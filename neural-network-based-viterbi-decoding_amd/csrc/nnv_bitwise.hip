@@ -32,12 +32,18 @@ struct nnv_bitwise_handle {
   int32_t num_cus;
   int32_t groups;      // ceil(n_input / 8)
   float *stream_dev;   // [pos][group][lane][4]
+  // K4d in f16x3: hi / lo f16 fragments per step of 16 inputs
+  int32_t single16_ok;
+  int32_t steps;       // ceil(n_input / 16)
+  uint16_t *single16_dev;   // [pos][step][hi | lo][lane 64][8 halfs]
 };
 
 namespace {
 // Banks of up to this many positions run as one K4d launch per position.  300 k rows of 1036 inputs, same box: one
 // position 0.254 ms (K4b, 32-column tile: 0.263), two 0.51 (K4b's 4-position column tile: 0.69), three 0.76 (0.68).
 constexpr int kSingleMaxPositions = 2;
+// f16x3: one position 0.242 ms (the 128-column f16x3 tile: 0.415), two 0.48 (0.414): only a single position
+constexpr int kSingle16MaxPositions = 1;
 // K4c from this many positions on: below, a wave per position leaves waves idle and quantises the run to
 // ceil(P / 16) rounds (measured: P = 32 4.96 vs 4.92 ms for K4b, 48: 6.96 vs 7.31, 64: 8.96 vs 9.77).
 constexpr int kStreamMinPositions = 33;
@@ -149,6 +155,37 @@ int32_t nnv_bitwise_prepack_ex(const nnv_bitwise_desc *d, int32_t precision, nnv
       }
     }
   }
+  // K4d, f16x3: position p, step s, plane (hi | lo), lane, element e holds W1[p][16 s + 8 (lane >> 5) + e][lane & 31]
+  h->single16_ok = 0;
+  h->single16_dev = nullptr;
+  h->steps = static_cast<int32_t>((K + 15) / 16);
+  if (precision == NNV_PRECISION_F16X3 && P <= kSingle16MaxPositions && nnv::bank_single16_eligible(h->steps, K)) {
+    std::vector<uint16_t> frag(static_cast<size_t>(P * h->steps * 1024), 0);
+    for (int64_t pos = 0; pos < P; ++pos) {
+      const float *W1 = d->W1_host + pos * K * H;
+      for (int64_t st = 0; st < h->steps; ++st) {
+        uint16_t *hi = frag.data() + (pos * h->steps + st) * 1024, *lo = hi + 512;
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int64_t k = 16 * st + 8 * (lane >> 5) + e, j = lane & 31;
+            if (k < K && j < H) {
+              const float v = W1[k * H + j];
+              hi[lane * 8 + e] = nnv::f32_to_f16(v);
+              lo[lane * 8 + e] = nnv::f32_to_f16(v - nnv::f16_to_f32(hi[lane * 8 + e]));
+            }
+          }
+      }
+    }
+    if (hipMalloc(reinterpret_cast<void **>(&h->single16_dev), frag.size() * sizeof(uint16_t)) == hipSuccess) {
+      if (hipMemcpy(h->single16_dev, frag.data(), frag.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess &&
+          nnv::bank_single16_prepare(h->steps, dev) == NNV_OK) {
+        h->single16_ok = 1;
+      } else {
+        (void)hipFree(h->single16_dev);
+        h->single16_dev = nullptr;
+      }
+    }
+  }
   *out = h;
   return NNV_OK;
 }
@@ -157,8 +194,9 @@ int32_t nnv_bitwise_free(nnv_bitwise_handle *h) {
   if (!h) return NNV_OK;
   const hipError_t e = hipFree(h->dev);
   const hipError_t e2 = h->stream_dev ? hipFree(h->stream_dev) : hipSuccess;
+  const hipError_t e3 = h->single16_dev ? hipFree(h->single16_dev) : hipSuccess;
   delete h;
-  return (e == hipSuccess && e2 == hipSuccess) ? NNV_OK : NNV_ERR_HIP;
+  return (e == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? NNV_OK : NNV_ERR_HIP;
 }
 
 int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, int64_t n_rows,
@@ -179,11 +217,12 @@ int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, 
   // and for the tests that hold the paths against each other; NNV_BANK_STREAM_MIN overrides K4c's lower bound.
   const bool x16 = h->n_input % 4 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 16 == 0;
   const auto off = [](const char *name) { const char *e = getenv(name); return e && e[0] == '0'; };
+  const bool use_single16 = h->single16_ok && x16 && !off("NNV_BANK_SINGLE");   // f16x3 handles only
   const bool use_single = h->single_ok && x16 && !off("NNV_BANK_SINGLE");
   const char *min_env = getenv("NNV_BANK_STREAM_MIN");
   const int stream_min = min_env ? atoi(min_env) : kStreamMinPositions;
   const bool use_stream = !use_single && h->stream_ok && h->n_pos >= stream_min && !off("NNV_BANK_STREAM");
-  if (use_single || use_stream) {
+  if (use_single || use_stream || use_single16) {
     nnv::BankStreamParams q{};
     q.x = x_dev;
     q.row_stride = h->n_input;
@@ -205,10 +244,16 @@ int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, 
     if (use_stream) return nnv::bank_stream_launch(q, h->num_cus, h->device, static_cast<hipStream_t>(stream));
     q.n_pos = 1;
     q.w_bytes = h->groups * 1024;
+    if (use_single16) {                              // slots are steps of 16 inputs, fragments hi | lo f16
+      q.groups = h->steps;
+      q.w = reinterpret_cast<const float *>(h->single16_dev);
+      q.w_bytes = h->steps * 2048;
+    }
     for (int64_t pos = 0; pos < h->n_pos; ++pos) {   // one launch per position, stream-ordered
-      const nnv_status e = nnv::bank_single_launch(q, h->num_cus, h->device, static_cast<hipStream_t>(stream));
+      const nnv_status e = use_single16 ? nnv::bank_single16_launch(q, h->num_cus, h->device, static_cast<hipStream_t>(stream))
+                                        : nnv::bank_single_launch(q, h->num_cus, h->device, static_cast<hipStream_t>(stream));
       if (e != NNV_OK) return e;
-      q.w += static_cast<int64_t>(h->groups) * 256;
+      q.w += use_single16 ? static_cast<int64_t>(h->steps) * 512 : static_cast<int64_t>(h->groups) * 256;
       q.bias += 32;
       q.head_w += 64;
       q.head_b += 2;

@@ -18,6 +18,8 @@
 //  * the 16 partial 32 x 32 accumulators meet in LDS (64 KB, double-buffered): one barrier, every thread sums the 16
 //    partials of ONE (neuron, row) element in slice order, + bias, ReLU; one more barrier, one wave (rotating) runs the
 //    2-logit head: sequential fmaf chain over the hidden units, bias, ReLU, first maximum -- as K4b / K4c.
+// The same kernel serves the f16x3 mode of a single position (F16 = true: steps of 16 inputs, hi / lo planes split in
+// registers, three 16-bit MFMAs per step): 0.24 ms against 0.41 ms on the 128-column f16x3 tile.
 // Summation order: per slice k ascending, then the slices in ascending order -- deterministic and a function of the row
 // alone, but NOT K4b's single chain: hidden values differ from the tiled path's in the last bits (same 1e-5 contract
 // against float64; the tests hold both against the oracle).
@@ -33,6 +35,8 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 
 namespace {
 
@@ -53,9 +57,27 @@ constexpr int kLdsFloats = 2 * kPartFloats + 2 * kHidFloats + 64 + 4;   // + hea
 
 // The tile loop of a wave that owns NG fragment groups.  No branch inside the group loop: the waits on the rows are
 // counts (the loads return in order), never "everything outstanding" -- which would include the next tile's rows.
-template <int NG>
-__device__ __forceinline__ void single_run(const BankStreamParams &p, float *lds, const int g0, const bool kill_last) {
+// F16 (the f16x3 mode): a slot is a STEP of 16 inputs = one v_mfma_f32_32x32x16_f16 triple (w_lo x_hi + w_hi x_lo +
+// w_hi x_hi, fp32 accumulation, the order of the f16x3 GEMM); lane (row r, half kb) loads 32 bytes of its row per step
+// (two 16-byte loads) and splits them into hi / lo f16 planes in registers; the weights are packed as hi / lo fragments.
+// `kill_last` then counts the valid 16-byte chunks (1..4) of the row's LAST step instead of being a flag.
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, u32x4 &hi, u32x4 &lo) {
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 x = {v[2 * i], v[2 * i + 1]};
+    const f16x2 hh = __builtin_convertvector(x, f16x2);
+    const f32x2 rr = x - __builtin_convertvector(hh, f32x2);
+    hi[i] = __builtin_bit_cast(unsigned, hh);
+    lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, f16x2));
+  }
+}
+
+template <int NG, bool F16>
+__device__ __forceinline__ void single_run(const BankStreamParams &p, float *lds, const int g0, const int kill_last) {
   constexpr int NA = NG > 0 ? NG : 1;
+  constexpr int kSlotBytes = F16 ? 64 : 32;          // bytes of a row per slot
+  constexpr int kFragBytes = F16 ? 2048 : 1024;      // bytes of weight fragments per slot
   float *const hw_lds = lds + 2 * kPartFloats + 2 * kHidFloats;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -63,12 +85,15 @@ __device__ __forceinline__ void single_run(const BankStreamParams &p, float *lds
   const int r = lane & 31, h = lane >> 5;
   const unsigned lane_off = static_cast<unsigned>(lane) * 16u;
 
-  f32x4 w[NA];
+  f32x4 w[NA];                 // fp32: A fragments of 4 MFMAs; f16x3: the hi plane (8 halfs) ...
+  f32x4 w2[F16 ? NA : 1];      // ... and the lo plane
   {
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.groups * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.groups * kFragBytes, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < NG; ++j)
-      w[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane_off, (g0 + j) * 1024, 0));
+    for (int j = 0; j < NG; ++j) {
+      w[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane_off, (g0 + j) * kFragBytes, 0));
+      if constexpr (F16) w2[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane_off, (g0 + j) * kFragBytes + 1024, 0));
+    }
   }
   // this thread's element of the reduction: register 4q + e of lane l = hidden neuron 8q + 4 (l >> 5) + e of row l & 31
   const int red_n = 8 * (tid >> 8) + 4 * ((tid >> 7) & 1) + (tid & 3);
@@ -91,19 +116,29 @@ __device__ __forceinline__ void single_run(const BankStreamParams &p, float *lds
     const uint8_t *b = rows_left > 0 ? p.labels + t * 32 : nullptr;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(b), 0, static_cast<int>(bytes), 0x00020000);
   };
-  const unsigned x_off = static_cast<unsigned>((static_cast<int64_t>(r) * p.row_stride + 4 * h) * 4);   // lane's row + half
-  const int s_off = g0 * 32;                                                                            // slice start, bytes
+  const unsigned x_off = static_cast<unsigned>((static_cast<int64_t>(r) * p.row_stride + (F16 ? 8 : 4) * h) * 4);   // lane's row + half
+  const int s_off = g0 * kSlotBytes;                                                                    // slice start, bytes
   // The group the row ends in (K % 8 == 4) is the last one of one wave: the upper half of it belongs to the NEXT row
   // and must never be multiplied, not even by 0 (a NaN there would cross rows).  Those lanes load it through an offset
   // beyond every descriptor's range (num_records <= 0x7FFFF000, slice offsets < 2^30): the range check returns 0.
-  const unsigned x_off_last = (kill_last && h) ? 0x80000000u : x_off;
+  // (f16x3: the last step holds kill_last = 1..4 valid 16-byte chunks; this lane's two are chunks 2h and 2h + 1.)
+  const unsigned x_off_last = F16 ? ((kill_last && 2 * h >= kill_last) ? 0x80000000u : x_off)
+                                  : ((kill_last && h) ? 0x80000000u : x_off);
+  const unsigned x_off2 = x_off + 16u;
+  const unsigned x_off2_last = (kill_last && 2 * h + 1 >= kill_last) ? 0x80000000u : x_off2;
 
   f32x4 b[NA];
+  f32x4 b2[F16 ? NA : 1];      // f16x3: the second 16 bytes of the lane's 32
+  auto load_slot = [&](const __amdgpu_buffer_rsrc_t rs, int j) {
+    b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, j == NG - 1 ? x_off_last : x_off, s_off + j * kSlotBytes, 0));
+    if constexpr (F16)
+      b2[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, j == NG - 1 ? x_off2_last : x_off2, s_off + j * kSlotBytes, 0));
+  };
   {
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc(blockIdx.x);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-      b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, j == NG - 1 ? x_off_last : x_off, s_off + j * 32, 0));
+      load_slot(rs, j);
       __builtin_amdgcn_sched_barrier(0);   // in slot order, like the refills: the loop's waits are counts relative to that order
     }
   }
@@ -118,16 +153,26 @@ __device__ __forceinline__ void single_run(const BankStreamParams &p, float *lds
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-      const f32x4 c = b[j];
+      if constexpr (F16) {
+        u32x4 xh, xl;
+        split8(b[j], b2[j], xh, xl);
+        const f16x8 wh = __builtin_bit_cast(f16x8, w[j]), wl = __builtin_bit_cast(f16x8, w2[j]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, __builtin_bit_cast(f16x8, xh), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, __builtin_bit_cast(f16x8, xl), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, __builtin_bit_cast(f16x8, xh), acc, 0, 0, 0);
+      } else {
+        const f32x4 c = b[j];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j][e], c[e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j][e], c[e], acc, 0, 0, 0);
+      }
       // the next tile's groups into the registers just freed (refilled AFTER their consumers: no copies), kBurst
       // slots back to back: consecutive slots are consecutive 32-byte pieces of the same cache lines
-      if ((j + 1) % kBurst == 0 || j == NG - 1) {
+      constexpr int burst = F16 ? 1 : kBurst;
+      if ((j + 1) % burst == 0 || j == NG - 1) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = j - j % kBurst; i <= j; ++i) {
-          b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(next_rs, i == NG - 1 ? x_off_last : x_off, s_off + i * 32, 0));
+        for (int i = j - j % burst; i <= j; ++i) {
+          load_slot(next_rs, i);
           __builtin_amdgcn_sched_barrier(0);   // keep the refills HERE and in slot order: the waits are counts relative to that order
         }
       }
@@ -185,7 +230,8 @@ __device__ __forceinline__ void single_run(const BankStreamParams &p, float *lds
   }
 }
 
-template <int G>   // = ceil(groups / 16): a wave owns G or G - 1 fragment groups (k-slice of at most 8 G inputs)
+// G = ceil(slots / 16): a wave owns G or G - 1 slots (fp32: fragment groups of 8 inputs; f16x3: steps of 16 inputs)
+template <int G, bool F16 = false>
 __global__ __launch_bounds__(kThreads) void bank_single_kernel(const BankStreamParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -196,17 +242,28 @@ __global__ __launch_bounds__(kThreads) void bank_single_kernel(const BankStreamP
   const int g0 = wave * base + (wave < rem ? wave : rem);
   // the wave whose LAST group is the one the row ends in (K % 8 == 4): that group's upper half belongs to the NEXT
   // row -- it is never multiplied, not even by 0
-  const bool kill_last = p.K % 8 != 0 && ng > 0 && g0 + ng == p.groups;
+  // (f16x3: the number of valid 16-byte chunks, 1..3, of a last step the row does not fill; 0 = nothing to kill)
+  const bool owns_last = ng > 0 && g0 + ng == p.groups;
+  const int kill_last = F16 ? ((owns_last && p.K % 16 != 0) ? (p.K % 16) / 4 : 0) : ((owns_last && p.K % 8 != 0) ? 1 : 0);
   float *const hw_lds = lds + 2 * kPartFloats + 2 * kHidFloats;
   if (tid < 64) hw_lds[tid] = p.head_w[tid];
   if (tid >= 64 && tid < 66) hw_lds[tid] = p.head_b[tid - 64];
   // Two copies of the tile loop, one per slice length; both run the same barriers the same number of times (the
   // trip count depends on the workgroup only).
-  if (ng == G) single_run<G>(p, lds, g0, kill_last);
-  else single_run<G - 1>(p, lds, g0, kill_last);
+  if (ng == G) single_run<G, F16>(p, lds, g0, kill_last);
+  else single_run<G - 1, F16>(p, lds, g0, kill_last);
 }
 
 using SingleFn = void (*)(const BankStreamParams);
+SingleFn single16_fn(int per_wave) {   // f16x3: steps of 16 inputs per wave
+  switch (per_wave) {
+    case 1: return bank_single_kernel<1, true>;
+    case 2: return bank_single_kernel<2, true>;
+    case 3: return bank_single_kernel<3, true>;
+    case 4: return bank_single_kernel<4, true>;
+    default: return bank_single_kernel<5, true>;
+  }
+}
 SingleFn single_fn(int per_wave) {
   switch (per_wave) {
     case 1: return bank_single_kernel<1>;
@@ -244,6 +301,38 @@ nnv_status bank_single_prepare(int groups, int device) {
     set[device][idx] = 1;
   }
   return NNV_OK;
+}
+
+// f16x3 variant: p.groups = steps of 16 inputs, p.w = [step][plane hi | lo][lane 64][8 halfs].  At most 5 steps per wave.
+bool bank_single16_eligible(int steps, int64_t row_stride) {
+  return (steps + kWaves - 1) / kWaves <= 5 && row_stride * 4 * 32 < (1LL << 30);
+}
+
+nnv_status bank_single16_prepare(int steps, int device) {
+  static int set[kMaxDevices][6] = {};
+  static std::mutex mu;
+  if (device < 0 || device >= kMaxDevices) return NNV_ERR_INVALID_ARGUMENT;
+  const int per_wave = (steps + kWaves - 1) / kWaves;
+  if (per_wave > 5) return NNV_ERR_UNSUPPORTED_SHAPE;
+  const std::lock_guard<std::mutex> lock(mu);
+  if (!set[device][per_wave]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(single16_fn(per_wave)), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLdsFloats * 4) != hipSuccess)
+      return NNV_ERR_HIP;
+    set[device][per_wave] = 1;
+  }
+  return NNV_OK;
+}
+
+nnv_status bank_single16_launch(const BankStreamParams &p, int num_cus, int device, hipStream_t stream) {
+  if (p.n_rows <= 0) return NNV_OK;
+  const nnv_status e = bank_single16_prepare(p.groups, device);   // a no-op after prepack
+  if (e != NNV_OK) return e;
+  int64_t blocks = p.n_blocks < num_cus ? p.n_blocks : num_cus;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(single16_fn((p.groups + kWaves - 1) / kWaves), dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
+                     kLdsFloats * 4, stream, p);
+  return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 
 // p describes ONE position: every per-position pointer (w, bias, head_w, head_b, bits, head_act, labels, errors)

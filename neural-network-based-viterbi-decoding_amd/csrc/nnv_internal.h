@@ -345,6 +345,10 @@ nnv_status bank_stream_launch(const BankStreamParams &p, int num_cus, int device
 bool bank_single_eligible(int groups, int64_t row_stride);
 nnv_status bank_single_prepare(int groups, int device);
 nnv_status bank_single_launch(const BankStreamParams &p, int num_cus, int device, hipStream_t stream);
+// ... and its f16x3 variant: p.groups = steps of 16 inputs, p.w = [step][hi | lo][lane 64][8 halfs]
+bool bank_single16_eligible(int steps, int64_t row_stride);
+nnv_status bank_single16_prepare(int steps, int device);
+nnv_status bank_single16_launch(const BankStreamParams &p, int num_cus, int device, hipStream_t stream);
 
 // nnv_generator.hip
 nnv_status generate_launch(int32_t code, int32_t tile_bits, int64_t n_rows,

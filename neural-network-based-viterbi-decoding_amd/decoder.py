@@ -390,7 +390,9 @@ class BitwiseBank:
         explicit = precision is not None
         self.precision = _resolve_precision(precision)
         if self.precision == "f16x3" and not explicit and len(models) < 2:
-            self.precision = "f32"    # one position is HBM-shaped: the 32-column fp32 tile (0.29 ms) beats the f16x3 GEMM (0.42 ms)
+            # one position is HBM-shaped: fp32 0.25 ms (K4d) / 0.26 ms (32-column tile); f16x3 0.24 ms where its K4d variant
+            # applies (n_input <= 1280, 16-byte rows) but 0.42 ms on the 128-column f16x3 tile elsewhere
+            self.precision = "f32"
         self._lib = _cabi.load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()
                                    if device is None else torch.device(device).index or 0)

@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=300_000)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--positions", type=int, nargs="+", default=[1, 2, 3, 4])
+ap.add_argument("--precision", default="f32")
 args = ap.parse_args()
 cfg = bw.BitwiseDecoderConfig()
 n = args.rows
@@ -33,13 +34,13 @@ def timed(fn, steps):
     return e0.elapsed_time(e1) / steps, r
 
 
-out = {"rows": n, "n_input": cfg.n_input, "hbm_bytes_per_position_pass": 4 * cfg.n_input * n, "legs": []}
+out = {"precision": args.precision, "rows": n, "n_input": cfg.n_input, "hbm_bytes_per_position_pass": 4 * cfg.n_input * n, "legs": []}
 for P in args.positions:
     models = []
     for p in range(P):
         wp, bp = bw.initialize_weights(cfg, rng=np.random.RandomState(100 + p))
         models.append((wp["h1"], bp["b1"], wp["out"], np.array([0.01, 0.0], np.float32)))
-    bank = BitwiseBank(models)
+    bank = BitwiseBank(models, precision=args.precision)
     os.environ.pop("NNV_BANK_SINGLE", None)
     ms_d, r_d = timed(lambda: bank.decode(x), args.steps)
     os.environ["NNV_BANK_SINGLE"] = "0"
