@@ -44,8 +44,12 @@ def test_header_cites_the_reference_for_each_compute_entry():
         assert needle in text, needle
 
 
+def header_abi_version():
+    return int(re.search(r"^#define\s+NNV_ABI_VERSION\s+(\d+)", open(HEADER).read(), re.M).group(1))
+
+
 def test_version_and_status_strings(lib):
-    assert lib.nnv_abi_version() == _cabi.NNV_ABI_VERSION == 5
+    assert lib.nnv_abi_version() == _cabi.NNV_ABI_VERSION == header_abi_version()
     assert lib.nnv_status_string(0) == b"ok"
     assert b"unsupported" in lib.nnv_status_string(2)
     assert lib.nnv_device_count() >= 0
@@ -94,3 +98,17 @@ def test_device_rule_status_codes(lib):
         assert lib.nnv_check_device(cur) == 0
         assert lib.nnv_check_device(cur + 1) == 1            # NNV_ERR_INVALID_ARGUMENT
     assert b"another device" in lib.nnv_status_string(1)
+
+
+def test_graft_entry_build_runs_end_to_end():
+    """The driver's "does it build" check: __graft_entry__.build() compiles the HIP library and the
+    oracle's C restatement, loads the library and compares its ABI with the header and the binding.
+    Run as the driver runs it (a fresh interpreter), so a stale literal in the entry point fails here
+    and not at round end."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], cwd=ROOT,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import __graft_entry__ as entry
+    assert entry.header_abi_version() == header_abi_version() == _cabi.NNV_ABI_VERSION
