@@ -131,8 +131,65 @@ def cpu_baseline(x_dev, labels_dev, Ws, bs, hip_cls, budget_s=12.0, torch_budget
     }
 
 
-def other_baseline_configs(dev, steps: int, net_headline):
-    """The other four BASELINE configs measured in the same run (never `value`; 3 and 4 at reduced size, labelled).
+CONFIG3_BLOCKS = 100_000_000       # BASELINE.json configs[3]: 100 M blocks of block_len 1024, block-sharded
+CONFIG3_ROWS_PER_BLOCK = 1024 // TILE_BITS
+CONFIG3_SNR_DB = tuple(range(7))   # "mixed-SNR sweep 0-6 dB": block i at (i mod 7) dB
+CONFIG3_SEED = 2024
+
+
+def config3_block_shard(net, dev, rank: int, world: int, n_blocks_total: int):
+    """BASELINE configs[3] -- the one config DEFINED as an N-GPU block shard -- at its stated size for ANY rank count:
+    (133,171) block_len=1024 as 128 tiles of b=8, `n_blocks_total` blocks (BASELINE: 100 M = 12.8 G rows) split into
+    contiguous block ranges over the `world` ranks (distributed.block_shard, remainder to the low ranks), block i at
+    SNR (i mod 7) dB, rows generated on the device chunk by chunk (generation INCLUDED in the time) and decoded with
+    per-SNR-bin counters, then ONE int64 SUM all-reduce of the [7, 4] counters -- the path's only collective.
+    The reference evaluates one SNR per run (src/fnn_viterbi_mixed_snr.py:452-460,813-845: test set drawn at
+    snr_db_vec[test_snr_index], one Session.run, accuracy + BER printed); here all seven bins are one pass.
+    The total work is fixed (this leg scales STRONGLY), and since the generator is keyed by the global row the
+    reduced counters are the same integers for every `world` -- `counters` in the record is there to be compared.
+    Called by EVERY rank (it contains collectives); returns the record on every rank."""
+    sig = [float(fv.DecoderConfig(snr_db=float(d)).sigma) for d in CONFIG3_SNR_DB]
+    rpb = CONFIG3_ROWS_PER_BLOCK
+    first_block, my_blocks = nd.block_shard(n_blocks_total, rank, world)
+    # warm-up: one small pass through the binned kernel variant (first-launch costs stay out of the time)
+    nd.decode_blocks_sharded(net, "133171", TILE_BITS, 7 * 64, rpb, sig, 1, 0, 1, chunk_rows=1 << 20, device=dev)
+    torch.cuda.synchronize(dev)
+    nd.barrier(dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    c = nd.decode_blocks_sharded(net, "133171", TILE_BITS, n_blocks_total, rpb, sig, CONFIG3_SEED, rank, world,
+                                 chunk_rows=1 << 25, device=dev)
+    torch.cuda.synchronize(dev)
+    mine = time.perf_counter() - t0
+    nd.barrier(dev)
+    elapsed = nd.max_over_ranks(time.perf_counter() - t0, device=dev)
+    per_rank_s = nd.gather_floats(mine, device=dev)
+    per_rank_blocks = nd.gather_ints(my_blocks, device=dev)
+    local = c.cpu().numpy().tolist()
+    nd.all_reduce_counters(c)              # RCCL: [7, 4] int64 SUM
+    c = c.cpu().numpy()
+    size = (f"BASELINE's {n_blocks_total // 1_000_000}M blocks" if n_blocks_total == CONFIG3_BLOCKS
+            else f"REDUCED: {n_blocks_total:,} of BASELINE's {CONFIG3_BLOCKS // 1_000_000}M blocks")
+    flop_row, _ = algorithmic_work([2 * TILE_BITS, 128, 64, 32, 2 ** TILE_BITS])
+    return {
+        "workload": f"{size} = {n_blocks_total * rpb:,} rows block-sharded over {world} rank(s) -- (133,171) block_len=1024 as "
+                    f"{rpb} tiles of b={TILE_BITS}, SNR of block i = i mod 7 dB, on-device generation included, "
+                    f"per-SNR-bin counters, one all-reduce",
+        "value": n_blocks_total / elapsed, "unit": "blocks/s", "seconds": elapsed, "dtype": net.precision,
+        "n_gpus": world, "scaling": "strong",
+        "blocks_total": n_blocks_total, "blocks_per_rank": per_rank_blocks, "seconds_per_rank": per_rank_s,
+        "first_block_this_rank": first_block,
+        "roofline_frac_of_fp32_mfma_peak_generation_included":
+            flop_row * rpb * n_blocks_total / elapsed / 1e12 / (MFMA_PEAK_TFLOPS["f32"] * world),
+        "ber_by_snr_db": {str(d): (float(c[d, 0] / c[d, 2]) if c[d, 2] else None) for d in CONFIG3_SNR_DB},
+        "fer_by_snr_db": {str(d): (float(c[d, 1] / c[d, 3]) if c[d, 3] else None) for d in CONFIG3_SNR_DB},
+        "counters": c.tolist(),
+        **({"counters_rank0_before_all_reduce": local} if world > 1 else {}),
+    }
+
+
+def other_baseline_configs(dev, steps: int):
+    """BASELINE configs[0], [1] and [4] measured in the same run (never `value`); configs[3] is config3_block_shard.
     configs[0] and configs[1]: (7,5) K=3 at block_len 20 / 100 as
     b = 10 tiles, network 20-128-64(-32)-1024 -- the 1024-class layer does not fit the LDS: the tiles that do not
     fit are streamed from L2 by every wave for its own rows (K1's stream variant).  Matched-filter weights of the reference's
@@ -169,25 +226,7 @@ def other_baseline_configs(dev, steps: int, net_headline):
                      "ber": float(c[0] / c[2]), "roofline_frac_of_fp32_mfma_peak": tf / MFMA_PEAK_TFLOPS["f32"],
                      "class_tiles_in_lds": netm.launch_info(n)["class_tiles_in_lds"], "class_tiles": dims[-1] // 32}
         netm.close()
-    # configs[3]: (133,171) block_len=1024 = 128 tiles of b=8, block i at SNR (i mod 7) dB; on-device generation
-    # INCLUDED, per-SNR-bin counters.  BASELINE names 100 M blocks over 8 GPUs: one GPU's share, 12.5 M blocks = 1.6 G
-    # rows, generated and decoded in 32 M-row chunks (also the `-m gpu` test test_mixed_snr_sweep_full_per_gpu_share).
     small = os.environ.get("NNV_BENCH_SMALL_LEGS") == "1"     # quick runs: the round-3 reduced sizes
-    n3 = 400_000 if small else 12_500_000                     # BASELINE: 100 M blocks over 8 GPUs = 12.5 M per GPU
-    sig = [float(fv.DecoderConfig(snr_db=float(d)).sigma) for d in range(7)]
-    nd.decode_blocks_sharded(net_headline, "133171", TILE_BITS, 7 * 64, 128, sig, 1, 0, 1, chunk_rows=1 << 20, device=dev)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    c3 = nd.decode_blocks_sharded(net_headline, "133171", TILE_BITS, n3, 128, sig, 2024, 0, 1, chunk_rows=1 << 25, device=dev)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    c3 = c3.cpu().numpy()
-    label3 = (f"REDUCED: {n3} blocks on one GPU (BASELINE: 100M over 8 GPUs)" if small else
-              f"ONE GPU's share of BASELINE's 100M blocks over 8 GPUs: {n3} blocks = {n3 * 128} rows")
-    out["configs[3]"] = {"workload": f"{label3} -- (133,171) block_len=1024 as "
-                                     f"128 tiles of b=8, SNR of block i = i mod 7 dB, generation included, per-SNR-bin counters",
-                         "value": n3 / dt, "unit": "blocks/s", "seconds": dt, "dtype": "f32",
-                         "ber_by_snr_db": {str(d): float(c3[d, 0] / c3[d, 2]) for d in range(7)}}
     # configs[4]: the recurrent decoder forward.  BASELINE says GRU; the reference builds an LSTM(20) seq2seq
     # (src/rnn_viterbi.py:289-318), and that is what runs, at BASELINE's 10 M blocks (also a `-m gpu` test).
     from nnviterbi_amd import rnn_viterbi as rv
@@ -230,7 +269,7 @@ def next_row_paths(dev, steps: int):
     forward (src/fnn_viterbi_seq_predict.py:293-336,343-414: window i = stream[2i : 2i+200], 200-500-500-500-500-2,
     tanh everywhere, argmax = the bit) over its default 1,000,000-window test stream, seeded random weights.
     K6 = the whole chain in ONE persistent launch (activations resident in LDS, csrc/nnv_wide_fused.hip); the
-    layer-at-a-time path K4 beside it (NNV_WIDE_FUSED=0, read per call by the C ABI)."""
+    layer-at-a-time path K4 beside it (the handle pinned with nnv_wide_set_path)."""
     from nnviterbi_amd import fnn_viterbi_seq_predict as sq
     from nnviterbi_amd.decoder import WideMLP
     cfg = sq.SequentialDecoderConfig()
@@ -245,27 +284,25 @@ def next_row_paths(dev, steps: int):
     flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     res = {}
-    for name, env in (("fused_one_launch_K6", None), ("layer_at_a_time_K4", "0")):
-        if env is None:
-            os.environ.pop("NNV_WIDE_FUSED", None)
-        else:
-            os.environ["NNV_WIDE_FUSED"] = env
-        try:
+    cls_by_path = {}
+    for name, path in (("fused_one_launch_K6", "fused"), ("layer_at_a_time_K4", "layered")):
+        net.set_path(path)                      # nnv_wide_set_path: the handle, not the environment, picks the kernel
+        r = net.decode_stream(stream, n)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(steps):
             r = net.decode_stream(stream, n)
-            torch.cuda.synchronize(dev)
-            e0.record()
-            for _ in range(steps):
-                r = net.decode_stream(stream, n)
-            e1.record()
-            torch.cuda.synchronize(dev)
-        finally:
-            os.environ.pop("NNV_WIDE_FUSED", None)
+        e1.record()
+        torch.cuda.synchronize(dev)
         ms = e0.elapsed_time(e1) / steps
-        res[name] = {"value": n / (ms * 1e-3), "unit": "decoded bits/s", "ms_per_step": ms,
+        cls_by_path[name] = r["cls32"]
+        res[name] = {"kernel": net.path, "value": n / (ms * 1e-3), "unit": "decoded bits/s", "ms_per_step": ms,
                      "roofline_frac_of_fp32_mfma_peak": flop * n / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f32"],
                      "ones_decoded": int(r["cls32"].sum().item())}
     net.close()
-    res["classes_differing_between_the_two_paths"] = None if len({v["ones_decoded"] for v in res.values()}) == 1 else "see ones_decoded"
+    a, b = cls_by_path.values()
+    res["classes_differing_between_the_two_paths"] = int((a != b).sum().item())
+    del cls_by_path, a, b
     out = {"sliding_window": {"workload": f"{n} windows of 200 over one received stream, {'-'.join(str(d) for d in dims)} tanh, "
                                           f"{flop} FLOP per decoded bit, exact fp32, untrained weights", **res}}
     del stream
@@ -286,51 +323,49 @@ def next_row_paths(dev, steps: int):
     bank = BitwiseBank(models, device=dev, precision="f32")
     flop_row = 2 * cfgb.n_input * cfgb.n_hidden_1 * P + 2 * cfgb.n_hidden_1 * 2 * P
     resb = {}
-    for name, env in (("rows_resident_first_layers_streamed_K4c", None), ("lds_tiled_gemm_K4b", "0")):
-        if env is None:
-            os.environ.pop("NNV_BANK_STREAM", None)
-        else:
-            os.environ["NNV_BANK_STREAM"] = env
-        try:
+    bits_by_path = {}
+    for name, path in (("rows_resident_first_layers_streamed_K4c", "stream"), ("lds_tiled_gemm_K4b", "tiled")):
+        bank.set_path(path)
+        rb = bank.decode(xb)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(2):
             rb = bank.decode(xb)
-            torch.cuda.synchronize(dev)
-            e0.record()
-            for _ in range(2):
-                rb = bank.decode(xb)
-            e1.record()
-            torch.cuda.synchronize(dev)
-        finally:
-            os.environ.pop("NNV_BANK_STREAM", None)
+        e1.record()
+        torch.cuda.synchronize(dev)
         ms = e0.elapsed_time(e1) / 2
-        resb[name] = {"value": nb * P / (ms * 1e-3), "unit": "decided bits/s", "ms_per_step": ms,
+        bits_by_path[name] = rb["bits"]
+        resb[name] = {"kernel": bank.path_for(xb), "value": nb * P / (ms * 1e-3), "unit": "decided bits/s", "ms_per_step": ms,
                       "roofline_frac_of_fp32_mfma_peak": flop_row * nb / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f32"],
                       "ones_decided": int(rb["bits"].sum(dtype=torch.int64).item())}
     bank.close()
-    resb["decided_bits_identical"] = len({v["ones_decided"] for v in resb.values()}) == 1
+    a, b = bits_by_path.values()
+    resb["decided_bits_identical"] = bool(torch.equal(a, b))       # the bytes, not their sum
+    del bits_by_path, a, b, rb
     out["bitwise_bank"] = {"workload": f"{P} bit positions x {nb} rows, {cfgb.n_input}-{cfgb.n_hidden_1}-2 ReLU per position, "
                                        f"exact fp32, untrained weights, one launch", **resb}
     # ... and ONE position, the reference's own call shape (one trained network per run): HBM-shaped.  K4d = the
     # contraction split over the 16 waves, rows straight from HBM into the MFMA operand (csrc/nnv_bitwise_single.hip).
     one = BitwiseBank(models[:1], device=dev, precision="f32")
     res1 = {}
-    for name, env in (("k_split_rows_from_hbm_K4d", None), ("lds_tiled_gemm_K4b", "0")):
-        if env is not None:
-            os.environ["NNV_BANK_SINGLE"] = env
-        try:
-            for _ in range(3):
-                r1 = one.decode(xb)
-            torch.cuda.synchronize(dev)
-            e0.record()
-            for _ in range(20):
-                r1 = one.decode(xb)
-            e1.record()
-            torch.cuda.synchronize(dev)
-        finally:
-            os.environ.pop("NNV_BANK_SINGLE", None)
+    bits1 = {}
+    for name, path in (("k_split_rows_from_hbm_K4d", "single"), ("lds_tiled_gemm_K4b", "tiled")):
+        one.set_path(path)
+        for _ in range(3):
+            r1 = one.decode(xb)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(20):
+            r1 = one.decode(xb)
+        e1.record()
+        torch.cuda.synchronize(dev)
         ms = e0.elapsed_time(e1) / 20
-        res1[name] = {"value": nb / (ms * 1e-3), "unit": "rows/s", "ms_per_step": ms,
+        bits1[name] = r1["bits"]
+        res1[name] = {"kernel": one.path_for(xb), "value": nb / (ms * 1e-3), "unit": "rows/s", "ms_per_step": ms,
                       "roofline_frac_of_hbm_peak": (4 * cfgb.n_input + 1) * nb / (ms * 1e-3) / 8.0e12,
                       "ones_decided": int(r1["bits"].sum(dtype=torch.int64).item())}
+    a, b = bits1.values()
+    res1["decided_bits_differing"] = int((a != b).sum().item())    # another summation order: rounding-level ties may differ
     one.close()
     out["bitwise_one_position"] = {"workload": f"1 bit position x {nb} rows, {cfgb.n_input}-{cfgb.n_hidden_1}-2 ReLU, exact fp32, "
                                                f"untrained weights ({4 * cfgb.n_input + 1} algorithmic bytes per row)", **res1}
@@ -567,6 +602,9 @@ def main():
     ap.add_argument("--blocks-per-gpu", type=int, default=BASELINE_BLOCKS_PER_GPU)
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("NNV_LAUNCH_TIMEOUT_S", "300")),
                     help="bare `--gpus N` only: seconds the self-launched ranks get before they are terminated")
+    ap.add_argument("--config3-blocks", type=int, default=None,
+                    help="total blocks of the configs[3] block-shard leg (default: BASELINE's 100 M; "
+                         "NNV_BENCH_SMALL_LEGS=1: 3.2 M); 0 skips the leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="N = 1 only: skip the two rocprofv3 --pmc child passes and replay profiles/pmc_traffic.json")
@@ -587,9 +625,12 @@ def main():
     # rocprofv3's tracing environment on top of their own --pmc (the combination the pool refuses)
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.precision == "f32" and not args.no_live_traffic
-            and not under_profiler
-            and os.environ.get("NNV_BENCH_LIVE_TRAFFIC", "1") != "0" and torch.cuda.device_count() > 0):
-        live = live_traffic(args.blocks_per_gpu)                      # child processes; nothing here touched the GPU yet
+            and not under_profiler and os.environ.get("NNV_BENCH_LIVE_TRAFFIC", "1") != "0"
+            and torch.cuda.device_count() > 0):
+        # the passes are fresh child processes.  device_count() above only counts devices (on this image it does not
+        # create a HIP context; if it ever did, the children would still be safe -- they are separate processes
+        # started with Popen, not forks of an initialised runtime)
+        live = live_traffic(args.blocks_per_gpu)
 
     _stage("started")
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -724,6 +765,19 @@ def main():
         f16_out_err = float((net3.forward(x[:m]) - net.forward(x[:m])).abs().max().item())
     net3.close()
 
+    # ---- BASELINE configs[3]: the N-GPU block-shard config, at its stated size over however many ranks there are ----
+    n3 = args.config3_blocks
+    if n3 is None:
+        n3 = 3_200_000 if os.environ.get("NNV_BENCH_SMALL_LEGS") == "1" else CONFIG3_BLOCKS
+    config3 = None
+    if n3 > 0 and args.precision == "f32":
+        _stage("configs[3] block-shard leg")
+        try:      # after the headline measurement: a failure here must not cost the line
+            config3 = config3_block_shard(net, dev, rank, world, n3)
+        except Exception as e:   # noqa: BLE001  (reported, never silently dropped)
+            config3 = {"error": f"rank {rank}: {type(e).__name__}: {e}"}
+        _stage("configs[3] done")
+
     if rank == 0:
         flop_row, bytes_row = algorithmic_work(dims)
         launch_s = kernel_ms / 1e3 / args.steps
@@ -776,11 +830,14 @@ def main():
                     "(tests/test_gpu_f16_mode.py states its own tolerance); BASELINE's bar for it is |dBER| <= 1e-4",
         }
         # the legs below come after the headline measurement: a failure in one of them must not cost the line
+        out["other_baseline_configs"] = {}
         if world == 1:
             try:
-                out["other_baseline_configs"] = other_baseline_configs(dev, max(3, args.steps // 2), net)
+                out["other_baseline_configs"] = other_baseline_configs(dev, max(3, args.steps // 2))
             except Exception as e:   # noqa: BLE001  (reported, never silently dropped)
                 out["other_baseline_configs"] = {"error": f"{type(e).__name__}: {e}"}
+        if config3 is not None:
+            out["other_baseline_configs"]["configs[3]"] = config3
         if world == 1:
             try:
                 out["next_rows"] = next_row_paths(dev, max(3, args.steps // 4))
@@ -794,7 +851,10 @@ def main():
             except Exception as e:   # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
-    nd.barrier(dev)
+    try:
+        nd.barrier(dev)
+    except Exception:   # noqa: BLE001  (a rank that failed in a side leg: the line is already out)
+        pass
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -18,7 +18,9 @@
  *     every launch is stream-ordered and returns without synchronising;
  *   - every function returns an nnv_status (0 = NNV_OK); no exceptions, no
  *     global mutable state besides a kernel-attribute cache kept per (device,
- *     kernel), so one process may drive several GPUs;
+ *     kernel), so one process may drive several GPUs; the library reads NO
+ *     environment variable: which kernel a call runs is a function of the
+ *     handle and the call's arguments alone (nnv_*_set_path pins it per handle);
  *   - a handle belongs to the HIP device that was current when it was packed:
  *     every launch entry compares that device with the calling thread's current
  *     device FIRST and returns NNV_ERR_INVALID_ARGUMENT on a mismatch (nothing is
@@ -35,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NNV_ABI_VERSION 5 /* 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS */
+#define NNV_ABI_VERSION 6 /* 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS; 6: + nnv_wide_set_path / _get_path, nnv_bitwise_set_path / _path_for (no environment switches any more) */
 #define NNV_MAX_LAYERS 4 /* dense layers incl. the output layer */
 
 typedef enum nnv_status {
@@ -239,7 +241,8 @@ int32_t nnv_awgn_generate_f32(int32_t code, int32_t tile_bits, int64_t n_rows,
  *  - otherwise one fp32-MFMA GEMM launch per layer (bias + activation fused),
  *    activations in the caller-provided HBM workspace, a small head kernel for
  *    <= 32 classes or a row-argmax for wider class layers.
- *    (NNV_WIDE_FUSED=0 in the environment, read per call, forces this path.)
+ *    (nnv_wide_set_path pins a handle to either; the default is the first
+ *    whenever the shape allows it.)
  * ------------------------------------------------------------------------ */
 #define NNV_WIDE_MAX_LAYERS 8
 
@@ -263,6 +266,21 @@ typedef struct nnv_wide_handle nnv_wide_handle;
 /* Replaces build_network's variables (src/fnn_viterbi_seq_predict.py:343-414). */
 int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out);
 int32_t nnv_wide_free(nnv_wide_handle *h);
+
+/* Kernel choice of a wide handle (ABI 6). */
+typedef enum nnv_wide_path {
+  NNV_WIDE_PATH_AUTO = 0,    /* the one-launch chain (K6) when the handle holds its packing, else layered */
+  NNV_WIDE_PATH_FUSED = 1,   /* K6, nnv_wide_fused.hip */
+  NNV_WIDE_PATH_LAYERED = 2  /* one GEMM launch per layer (K4), nnv_dense.hip */
+} nnv_wide_path;
+
+/* Pins the handle to one kernel (parity tests hold the two against each other; A/B timing).  FUSED on a handle
+ * whose shape K6 does not take returns NNV_ERR_UNSUPPORTED_SHAPE and changes nothing.  Not to be called while
+ * another thread decodes with the same handle. */
+int32_t nnv_wide_set_path(nnv_wide_handle *h, int32_t path);
+/* The kernel nnv_wide_decode_f32 runs on this handle: NNV_WIDE_PATH_FUSED or NNV_WIDE_PATH_LAYERED
+ * (negative nnv_status for a NULL handle). */
+int32_t nnv_wide_get_path(const nnv_wide_handle *h);
 
 /* Bytes of workspace needed to process `chunk_rows` rows at a time. */
 int64_t nnv_wide_workspace_bytes(const nnv_wide_handle *h, int64_t chunk_rows);
@@ -297,14 +315,14 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev,
  * (32 columns per position) and finishes each position's 2-logit head in the
  * GEMM epilogue: one launch, every row read once per 4 positions' tile, the
  * hidden activations never leave the chip.
- * Since round 4 the fp32 bank picks its kernel by size: >= 33 positions run
- * with 32 received rows resident in LDS and every position's first layer
- * streamed from L2 into the MFMA A operand (same results as the tiled GEMM bit
- * for bit; NNV_BANK_STREAM=0 in the environment, read per call, keeps the
- * tiled GEMM); 1-2 positions (the reference's own call shape is ONE per run)
+ * The fp32 bank picks its kernel by size: >= 33 positions run with 32
+ * received rows resident in LDS and every position's first layer streamed
+ * from L2 into the MFMA A operand (K4c; same results as the tiled GEMM K4b
+ * bit for bit); 1-2 positions (the reference's own call shape is ONE per run)
  * with 16-byte aligned rows run one HBM-streaming launch per position, the
- * contraction split over the waves (same tolerances, another summation order;
- * NNV_BANK_SINGLE=0 keeps the tiled GEMM).
+ * contraction split over the waves (K4d; same tolerances, another summation
+ * order); everything else the LDS-tiled GEMM.  nnv_bitwise_set_path pins a
+ * handle to one of them.
  * ------------------------------------------------------------------------ */
 typedef struct nnv_bitwise_desc {
   int32_t n_input;        /* 2 (constraint_length + block_length); even           */
@@ -324,6 +342,23 @@ int32_t nnv_bitwise_prepack(const nnv_bitwise_desc *net, nnv_bitwise_handle **ou
  * accumulators; every first-layer |weight| < 65504).  ABI 4. */
 int32_t nnv_bitwise_prepack_ex(const nnv_bitwise_desc *net, int32_t precision, nnv_bitwise_handle **out);
 int32_t nnv_bitwise_free(nnv_bitwise_handle *h);
+
+/* Kernel choice of a bank handle (ABI 6). */
+typedef enum nnv_bitwise_path {
+  NNV_BITWISE_PATH_AUTO = 0,   /* by size, as described above */
+  NNV_BITWISE_PATH_TILED = 1,  /* K4b: stacked first layers as one LDS-tiled GEMM, heads in its epilogue */
+  NNV_BITWISE_PATH_STREAM = 2, /* K4c: rows resident in LDS, first layers streamed from L2 (fp32, >= 2 positions) */
+  NNV_BITWISE_PATH_SINGLE = 3  /* K4d: one HBM-streaming launch per position (banks of <= 2 positions; f16x3: 1) */
+} nnv_bitwise_path;
+
+/* Pins the handle to one kernel.  A path whose packing the handle does not hold (K4c on a one-position or f16x3
+ * bank, K4d on a large one) returns NNV_ERR_UNSUPPORTED_SHAPE and changes nothing.  A pinned K4d still needs
+ * 16-byte aligned rows per call; calls that cannot take it run K4b (nnv_bitwise_path_for tells).  Not to be
+ * called while another thread decodes with the same handle. */
+int32_t nnv_bitwise_set_path(nnv_bitwise_handle *h, int32_t path);
+/* The kernel nnv_bitwise_decode_f32 would run for rows at x_dev: NNV_BITWISE_PATH_TILED / _STREAM / _SINGLE
+ * (negative nnv_status for a NULL handle). */
+int32_t nnv_bitwise_path_for(const nnv_bitwise_handle *h, const float *x_dev);
 
 /*
  * Replaces P runs of  predictions = tf.argmax(pred, 1).eval({x: test_encoded})
@@ -414,8 +449,8 @@ int32_t nnv_mlp_decode_f32_timed(const nnv_mlp_handle *h, const float *x_dev,
  * variant a classes+counters call on aligned rows gets, weights
  * resident in LDS (1/0 for the output layer), rows per wave tile, depth,
  * n_classes}; info_host[8] = precision; info_host[9] = class-layer M-tiles (32
- * classes each) resident in LDS, the rest being swept by the workgroup through an
- * LDS ring filled from L2 (info_host must hold 10 ints). */
+ * classes each) resident in LDS, the rest being streamed from L2 by every wave
+ * for its own rows (info_host must hold 10 ints). */
 int32_t nnv_mlp_launch_info(const nnv_mlp_handle *h, int64_t n_rows,
                             int32_t *info_host);
 

@@ -15,7 +15,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("NNV_LIB") or os.path.join(_PKG_DIR, "libnnviterbi_hip.so")
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 
-NNV_ABI_VERSION = 5
+NNV_ABI_VERSION = 6
 NNV_MAX_LAYERS = 4
 NNV_OK = 0
 NNV_CODE_57 = 0
@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "nnv_mlp_forward_f32", "nnv_awgn_generate_f32",
     "nnv_mlp_decode_f32_timed", "nnv_mlp_launch_info",
     "nnv_wide_prepack", "nnv_wide_free", "nnv_wide_workspace_bytes", "nnv_wide_decode_f32",
+    "nnv_wide_set_path", "nnv_wide_get_path", "nnv_bitwise_set_path", "nnv_bitwise_path_for",
     "nnv_seq2seq_prepack", "nnv_seq2seq_free", "nnv_seq2seq_forward_f32",
     "nnv_bitwise_prepack", "nnv_bitwise_prepack_ex", "nnv_bitwise_free", "nnv_bitwise_decode_f32",
 )
@@ -54,6 +55,8 @@ class WideDesc(ctypes.Structure):
 
 
 NNV_ACTIVATION = {"tanh": 0, "relu": 1}
+NNV_WIDE_PATH = {"auto": 0, "fused": 1, "layered": 2}                 # nnv_wide_path
+NNV_BITWISE_PATH = {"auto": 0, "tiled": 1, "stream": 2, "single": 3}  # nnv_bitwise_path
 
 
 class Seq2SeqDesc(ctypes.Structure):
@@ -194,6 +197,14 @@ def load_library() -> ctypes.CDLL:
     lib.nnv_bitwise_decode_f32.restype = c.c_int32
     lib.nnv_bitwise_decode_f32.argtypes = [
         c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.nnv_wide_set_path.restype = c.c_int32
+    lib.nnv_wide_set_path.argtypes = [c.c_void_p, c.c_int32]
+    lib.nnv_wide_get_path.restype = c.c_int32
+    lib.nnv_wide_get_path.argtypes = [c.c_void_p]
+    lib.nnv_bitwise_set_path.restype = c.c_int32
+    lib.nnv_bitwise_set_path.argtypes = [c.c_void_p, c.c_int32]
+    lib.nnv_bitwise_path_for.restype = c.c_int32
+    lib.nnv_bitwise_path_for.argtypes = [c.c_void_p, c.c_void_p]
     if lib.nnv_abi_version() != NNV_ABI_VERSION:
         raise NNViterbiError(
             f"ABI mismatch: library {lib.nnv_abi_version()} != binding {NNV_ABI_VERSION}")

@@ -36,6 +36,7 @@ struct nnv_bitwise_handle {
   int32_t single16_ok;
   int32_t steps;       // ceil(n_input / 16)
   uint16_t *single16_dev;   // [pos][step][hi | lo][lane 64][8 halfs]
+  int32_t path;        // nnv_bitwise_path: AUTO, or the kernel nnv_bitwise_set_path pinned the handle to
 };
 
 namespace {
@@ -47,6 +48,20 @@ constexpr int kSingle16MaxPositions = 1;
 // K4c from this many positions on: below, a wave per position leaves waves idle and quantises the run to
 // ceil(P / 16) rounds (measured: P = 32 4.96 vs 4.92 ms for K4b, 48: 6.96 vs 7.31, 64: 8.96 vs 9.77).
 constexpr int kStreamMinPositions = 33;
+
+// The kernel a decode call on `h` over rows at `x_dev` runs.  AUTO: small banks one K4d launch per position (rows
+// straight from HBM, the contraction split over the waves); large banks K4c (rows resident in LDS, first layers
+// streamed); in between, and for anything neither takes, the LDS-tiled GEMM K4b.  A pinned path is taken when the
+// handle holds its packing and the rows allow it (K4d needs 16-byte aligned rows), else K4b.
+int resolve_path(const nnv_bitwise_handle *h, const float *x_dev) {
+  const bool x16 = h->n_input % 4 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 16 == 0;
+  const bool may_single = h->path == NNV_BITWISE_PATH_AUTO || h->path == NNV_BITWISE_PATH_SINGLE;
+  if ((h->single16_ok || h->single_ok) && x16 && may_single) return NNV_BITWISE_PATH_SINGLE;
+  if (h->stream_ok && ((h->path == NNV_BITWISE_PATH_AUTO && h->n_pos >= kStreamMinPositions) ||
+                       h->path == NNV_BITWISE_PATH_STREAM))
+    return NNV_BITWISE_PATH_STREAM;
+  return NNV_BITWISE_PATH_TILED;
+}
 }  // namespace
 
 extern "C" {
@@ -77,6 +92,7 @@ int32_t nnv_bitwise_prepack_ex(const nnv_bitwise_desc *d, int32_t precision, nnv
   h->device = dev;
   h->kpad = (d->n_input + nnv::kDenseBK - 1) / nnv::kDenseBK * nnv::kDenseBK;
   h->precision = precision;
+  h->path = NNV_BITWISE_PATH_AUTO;
   h->bn = (d->n_positions == 1 && precision == NNV_PRECISION_F32) ? 32 : 128;   // the f16x3 GEMM has the 128-column tile only
   h->mpad = (32 * d->n_positions + h->bn - 1) / h->bn * h->bn;
   const int64_t K = d->n_input, H = d->n_hidden, P = d->n_positions;
@@ -199,6 +215,23 @@ int32_t nnv_bitwise_free(nnv_bitwise_handle *h) {
   return (e == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? NNV_OK : NNV_ERR_HIP;
 }
 
+int32_t nnv_bitwise_set_path(nnv_bitwise_handle *h, int32_t path) {
+  if (!h) return NNV_ERR_INVALID_ARGUMENT;
+  switch (path) {
+    case NNV_BITWISE_PATH_AUTO:
+    case NNV_BITWISE_PATH_TILED: break;
+    case NNV_BITWISE_PATH_STREAM: if (!h->stream_ok) return NNV_ERR_UNSUPPORTED_SHAPE; break;
+    case NNV_BITWISE_PATH_SINGLE: if (!h->single_ok && !h->single16_ok) return NNV_ERR_UNSUPPORTED_SHAPE; break;
+    default: return NNV_ERR_INVALID_ARGUMENT;
+  }
+  h->path = path;
+  return NNV_OK;
+}
+
+int32_t nnv_bitwise_path_for(const nnv_bitwise_handle *h, const float *x_dev) {
+  return h ? resolve_path(h, x_dev) : -NNV_ERR_INVALID_ARGUMENT;
+}
+
 int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, int64_t n_rows,
                                uint8_t *bits_dev, float *act_dev, const uint8_t *labels_dev,
                                uint64_t *errors_dev, void *stream) {
@@ -211,17 +244,11 @@ int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, 
     const nnv_status dv = nnv::check_current_device(h->device);
     if (dv != NNV_OK) return dv;
   }
-  // Which kernel (fp32): small banks one K4d launch per position (rows straight from HBM, the contraction split over the
-  // waves); large banks K4c (rows resident in LDS, first layers streamed); in between, and for anything neither takes,
-  // the LDS-tiled GEMM K4b.  NNV_BANK_STREAM=0 / NNV_BANK_SINGLE=0, read per call, switch K4c / K4d off for A/B runs
-  // and for the tests that hold the paths against each other; NNV_BANK_STREAM_MIN overrides K4c's lower bound.
   const bool x16 = h->n_input % 4 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 16 == 0;
-  const auto off = [](const char *name) { const char *e = getenv(name); return e && e[0] == '0'; };
-  const bool use_single16 = h->single16_ok && x16 && !off("NNV_BANK_SINGLE");   // f16x3 handles only
-  const bool use_single = h->single_ok && x16 && !off("NNV_BANK_SINGLE");
-  const char *min_env = getenv("NNV_BANK_STREAM_MIN");
-  const int stream_min = min_env ? atoi(min_env) : kStreamMinPositions;
-  const bool use_stream = !use_single && h->stream_ok && h->n_pos >= stream_min && !off("NNV_BANK_STREAM");
+  const int path = resolve_path(h, x_dev);
+  const bool use_single16 = path == NNV_BITWISE_PATH_SINGLE && h->single16_ok;   // f16x3 handles only
+  const bool use_single = path == NNV_BITWISE_PATH_SINGLE && !use_single16;
+  const bool use_stream = path == NNV_BITWISE_PATH_STREAM;
   if (use_single || use_stream || use_single16) {
     nnv::BankStreamParams q{};
     q.x = x_dev;
@@ -282,9 +309,9 @@ int32_t nnv_bitwise_decode_f32(const nnv_bitwise_handle *h, const float *x_dev, 
   // bank_tile_order.json): row-block-major (round 2) 168 GB; groups of 2 / 3 / 4 / 5 / 6 / 8 / 16 / 32 column blocks
   // 93 / 74 / 61 / 63 / 62 / 61 / 92 / 168 GB -- A is re-read once per group ((128 / G) x 1.24 GB), and from G = 5 on
   // the slab no longer stays resident beside the streaming rows (4 MB of L2 per XCD).  Launch time is the same
-  // for every order (78.0-78.5 ms: the fp32 matrix pipe is the limiter, 0.78 of peak).  NNV_BANK_GROUP overrides
-  // (tuning only; 0 = the round-2 order).
-  static const int forced_group = [] { const char *e = getenv("NNV_BANK_GROUP"); return e ? atoi(e) : -1; }();
+  // for every order (78.0-78.5 ms: the fp32 matrix pipe is the limiter, 0.78 of peak).  (A/B builds only:
+  // NNV_BANK_GROUP overrides; 0 = the round-2 order.)
+  static const int forced_group = [] { const char *e = nnv::ab_env("NNV_BANK_GROUP"); return e ? atoi(e) : -1; }();
   const int64_t slab_bytes = static_cast<int64_t>(h->bn) * h->kpad * 4;
   int group = forced_group >= 0 ? forced_group : static_cast<int>((2400LL * 1024) / slab_bytes);
   if (group > p.nblk_m) group = p.nblk_m;

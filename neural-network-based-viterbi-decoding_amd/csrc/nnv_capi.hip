@@ -138,14 +138,14 @@ bool pack_network_f16x3(const nnv_mlp_desc *net, const PackedShape &s, std::vect
 // Fragment order: see nnv_internal.h.  The hidden layers are packed scaled by 2 log2(e) (their
 // accumulators then hold the argument of the exp2 in tanh z = 1 - 2/(1 + 2^{2 log2(e) z}), act16 in
 // nnv_mlp_decode.hip); the class layer keeps its scale (its raw pre-activations feed the argmax).
-// With kFoldF32 the kernel hands r = 1/(1 + 2^zeta) from layer to layer instead of tanh z = 1 - 2r,
+// The kernel hands r = 1/(1 + 2^zeta) from layer to layer instead of tanh z = 1 - 2r,
 // so layers >= 2 are packed as W' = -2 W (exact) and b' = b + sum_k W_k (double, one rounding).
 void pack_network(const nnv_mlp_desc *net, const PackedShape &s, std::vector<float> *out) {
   out->assign(static_cast<size_t>(s.hid_floats + s.out_floats + s.bias_floats), 0.f);
   float *w = out->data();
   constexpr double kTwoLog2e = 2.8853900817779268;
   auto scaled = [&](int l, double v) {
-    const double f = (nnv::kFoldF32 && l >= 1) ? -2.0 : 1.0;
+    const double f = l >= 1 ? -2.0 : 1.0;
     return static_cast<float>((l == net->depth - 1 ? f : f * kTwoLog2e) * v);
   };
   // layer 1
@@ -189,7 +189,7 @@ void pack_network(const nnv_mlp_desc *net, const PackedShape &s, std::vector<flo
       double b = 0.0;
       if (i < M) {
         b = net->b_host[l][i];
-        if (nnv::kFoldF32 && l >= 1)
+        if (l >= 1)
           for (int k = 0; k < K; ++k) b += net->W_host[l][static_cast<size_t>(k) * M + i];
         b *= sc;
       }

@@ -326,7 +326,7 @@ nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream) {
   if (blocks <= 0 || blocks > 0x7fffffffLL) return NNV_ERR_INVALID_ARGUMENT;
   // BK = 64 measured 6 % slower than BK = 32 on the 512x512 layers (more staging registers and LDS,
   // same MFMA count); kept as an instantiation for A/B runs only.
-  static const bool use64 = getenv("NNV_DENSE_BK64") != nullptr;
+  static const bool use64 = ab_env("NNV_DENSE_BK64") != nullptr;
   const dim3 grid(static_cast<unsigned>(blocks)), block(256);
   if (p.act != 1 && p.act != 2) return NNV_ERR_INVALID_ARGUMENT;
   if (p.bn != 128 && p.bn != 32) return NNV_ERR_INVALID_ARGUMENT;

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void head_argmax_f16x3_kernel(const HeadF16Par
 nnv_status dense_f16x3_launch(const DenseF16Params &p, bool gather, hipStream_t stream) {
   const int64_t blocks = (p.nblk_rows + 7) / 8 * 8 * p.nblk_m;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return NNV_ERR_INVALID_ARGUMENT;
-  static const bool use32 = getenv("NNV_DENSE16_BK32") != nullptr;  // tuning only
+  static const bool use32 = ab_env("NNV_DENSE16_BK32") != nullptr;  // A/B builds only
   if (gather)
     hipLaunchKernelGGL((dense_f16x3_kernel<true, 32>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
   else if (p.Kpad % 64 == 0 && !use32)

@@ -107,7 +107,7 @@ int default_threads() {
     int n = static_cast<int>(std::thread::hardware_concurrency());
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, CPU_COUNT(&set));
-    if (const char *e = getenv("NNV_HOST_THREADS")) n = atoi(e);
+    if (const char *e = nnv::ab_env("NNV_HOST_THREADS")) n = atoi(e);   // A/B builds only; the ABI's n_threads argument is the control
     return std::max(1, std::min(n, 8));   // 8 staging threads saturate the host DRAM beside the DMA engine
   }();
   return cached;

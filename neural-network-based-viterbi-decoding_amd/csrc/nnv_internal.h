@@ -10,6 +10,16 @@
 
 namespace nnv {
 
+// A/B scaffolding.  The shipped library reads NO environment variable and has no alternative code paths behind
+// compile-time switches: the kernel a call gets is a function of the handle and the call's arguments alone
+// (include/nnviterbi.h: "no global mutable state").  tools/build_variant.sh builds side libraries with
+// -DNNV_AB_BUILD, and only there do the tuning overrides below (workgroup size, band policy, tile sizes ...) exist.
+#ifdef NNV_AB_BUILD
+inline const char *ab_env(const char *name) { return getenv(name); }
+#else
+constexpr const char *ab_env(const char *) { return nullptr; }
+#endif
+
 // IEEE binary16 <-> binary32 on the host (round-to-nearest-even), used by the packers of the
 // hi/lo f16 operand planes (nnv_capi.hip, nnv_wide.hip).
 inline uint16_t f32_to_f16(float f) {
@@ -83,13 +93,8 @@ inline float f16_to_f32(uint16_t h) {
 constexpr int kPrecF32 = 0;
 constexpr int kPrecF16x3 = 1;
 constexpr int kPrecF16 = 2;   // single-product f16: the hi planes of the f16x3 layout only
-// fp32 mode: hidden activations travel as r = 1/(1+2^zeta) with tanh's affine map 1 - 2r folded
-// into the next layer's packed weights (as the f16x3 mode always does).  Kernel (act16) and packer
-// (pack_network) must agree; 0 only in A/B builds.
-#ifndef NNV_FOLD_F32
-#define NNV_FOLD_F32 1
-#endif
-constexpr bool kFoldF32 = NNV_FOLD_F32 != 0;
+// In every precision the hidden activations travel as r = 1/(1+2^zeta) with tanh's affine map 1 - 2r folded
+// into the next layer's packed weights: kernel (act16) and packers (pack_network*) agree on that.
 constexpr int kFragGroupFloats = 256;
 constexpr int kRowsPerTile = 32;  // batch rows per wave tile (MFMA N dim)
 
@@ -121,7 +126,7 @@ struct DecodeParams {
   int32_t mt_out;
   int32_t n_classes;
   int32_t out_in_lds;  // ALL output-layer groups are LDS resident
-  int32_t out_lds_tiles;  // class-layer M-tiles resident in LDS (the rest goes through the LDS ring)
+  int32_t out_lds_tiles;  // class-layer M-tiles resident in LDS (every wave streams the rest from L2 for its own rows)
   int32_t tile_bits;
   const int32_t *labels;
   int32_t *cls32;
@@ -138,18 +143,9 @@ struct DecodeParams {
 
 // K1 variants (template parameter VARIANT of mlp_decode_kernel; see nnv_mlp_decode.hip)
 constexpr int kVarGeneral = 0, kVarStream = 1, kVarLean = 2;
-// A/B build switches of K1's argmax (defaults = the shipped kernel)
-#ifndef NNV_DEFER_ARGMAX
-#define NNV_DEFER_ARGMAX 1
-#endif
-#ifndef NNV_KEEP_LDS
-#define NNV_KEEP_LDS 1
-#endif
-constexpr bool kDeferArgmax = NNV_DEFER_ARGMAX != 0;
 // The running argmax winner's 16 raw accumulators are parked in a per-lane LDS slot by exec-masked
-// ds_write_b128 (no VALU) instead of 16 v_cndmask per class tile: 64 bytes per thread, reserved by
-// decode_plan (0 = A/B builds: kept in registers).
-constexpr bool kKeepLds = kDeferArgmax && NNV_KEEP_LDS != 0;
+// ds_write_b128 (no VALU) instead of 16 v_cndmask per class tile: 64 bytes per thread, reserved by decode_plan.
+constexpr int kKeepSlotBytes = 64;
 
 // KB of packed weights per class M-tile: fp32 / f16x3 4 per k-tile of 32 inputs, f16 2
 constexpr int class_tile_kb(int prec, int kt_out) { return (prec == kPrecF16 ? 2 : 4) * kt_out; }
@@ -185,7 +181,7 @@ nnv_status decode_supported(const PackedShape &s);
 // threads: the workgroup size picked ONCE at prepack (decode_pick_threads) and kept in the handle, so a
 // launch is table lookups + hipLaunchKernel, without runtime attribute queries.
 int decode_pick_threads(const PackedShape &s);
-// decides s->streams (class layer resident or swept through the LDS ring) and returns the workgroup size
+// decides s->streams (class layer LDS resident, or partly streamed from L2 by every wave) and returns the workgroup size
 int decode_configure(PackedShape *s, int lds_limit);
 nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
                        int lds_limit, int threads, LaunchPlan *plan);

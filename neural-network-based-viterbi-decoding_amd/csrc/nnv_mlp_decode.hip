@@ -35,15 +35,13 @@
 
 #include "nnv_internal.h"
 
-#ifndef NNV_CLASS_GROUP
-#define NNV_CLASS_GROUP 2
-#endif
-// product blocks of the streamed class tiles in flight per wave (A/B builds: 1, 4; must divide the units per tile)
-#ifndef NNV_STREAM_DEPTH
-#define NNV_STREAM_DEPTH 2
-#endif
-
 namespace nnv {
+
+// lean variant: class tiles whose MFMAs are issued before their argmax work (measured: 1 is 2 % slower, 4 spills)
+constexpr int kClassGroup = 2;
+// stream variant: product blocks of the streamed class tiles in flight per wave (must divide the units per tile;
+// measured 1 / 2 / 4 on configs[1]: 0.87 / 0.905 / 0.90 of the fp32 MFMA peak)
+constexpr int kStreamDepth = 2;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -215,17 +213,11 @@ __device__ __forceinline__ f32x16 init_acc(const float *bias_tile, int half) {
 //  prepack: pack_network / pack_network_f16x3 in nnv_capi.hip): 3 VALU instructions per activation
 //  (v_exp, v_add, v_rcp) instead of 4.  On gfx950 the fp32 MFMA does not co-execute with VALU work,
 //  so the 112 FMAs per tile this removes are ~1.4 % of the kernel time; outputs stay within 3e-6 of
-//  the float64 restatement (contract 1e-5).  kFoldF32 = false (-DNNV_FOLD_F32=0, A/B builds only)
-//  keeps a = tanh(z) = fma(-2, r, 1) between fp32 layers.
+//  the float64 restatement (contract 1e-5).
 //  Limits stay exact: zeta -> +inf gives rcp(inf) = 0 (tanh 1), -inf gives rcp(1) = 1 (tanh -1).
-template <int PREC>
 __device__ __forceinline__ void act16(f32x16 &acc) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r]));
-    if constexpr (PREC == kPrecF32 && !kFoldF32) acc[r] = __builtin_fmaf(-2.0f, rr, 1.0f);
-    else acc[r] = rr;
-  }
+  for (int r = 0; r < 16; ++r) acc[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r]));
 }
 
 // fp32 tanh returns exactly +-1.0f beyond |z| ~ 9.011 (1 - tanh z < 2^-25), for
@@ -239,10 +231,6 @@ __device__ __forceinline__ void act16(f32x16 &acc) {
 constexpr float kTanhSat = 9.011f;
 // from here up distinct pre-activations share an fp32 tanh value over spans wider than 0.25 in z
 constexpr float kFlatBand = 7.9f;
-#ifndef NNV_FLAT_TOP
-#define NNV_FLAT_TOP 1
-#endif
-constexpr bool kFlatTopPath = NNV_FLAT_TOP != 0;
 
 template <int G1, bool VEC_ONLY>
 __device__ __forceinline__ void load_x(const DecodeParams &p, int64_t tile,
@@ -282,7 +270,8 @@ __device__ __forceinline__ void load_x_lean(const char *tile_base, unsigned lane
   }
 }
 
-#ifdef NNV_DIAG  // separate diagnostic build only: per-phase s_memtime sums of (block 0, wave 0)
+#if defined(NNV_AB_BUILD) && defined(NNV_DIAG)  // diagnostic build only (tools/build_variant.sh): per-phase s_memtime sums of (block 0, wave 0)
+#define NNV_DIAG_ON 1
 __device__ unsigned long long g_diag[16];
 #define NNV_STAMP(slot)                                                                  \
   do {                                                                                   \
@@ -336,7 +325,6 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   if (threadIdx.x == 0) *tile_ctr = 0u;
   if (threadIdx.x < kMaxBins * 4) bin_ctr[threadIdx.x] = 0u;
   // behind them: the argmax winner slots (64 B per thread)
-  constexpr bool KEEP_LDS = kKeepLds;
   float *const keep_base = reinterpret_cast<float *>(bin_ctr + kMaxBins * 4);
   constexpr int GPT = KT_OUT * KTF / kFragGroupFloats;  // fragment groups per class tile
 
@@ -385,14 +373,13 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     }
   };
   if (tile < p.n_tiles) fetch_x(tile, xr);
-#ifdef NNV_DIAG
+#ifdef NNV_DIAG_ON
   unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long diag_last = __builtin_amdgcn_s_memtime();
   unsigned long long diag_tiles = 0;
 #endif
 
   while (tile < p.n_tiles) {
-    constexpr bool valid = true;   // (the round-3 ring ran waves without a tile through its barriers; gone)
     const int64_t next_tile = grab_tile();
     float xn[XN];
     // The packed weights in LDS never change, so LLVM would hoist every
@@ -409,7 +396,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     ActTile<PREC> ha[NHID == 1 ? MTA : 1];
     ActTile<PREC> hb[NHID >= 2 ? MTB : 1];
     ActTile<PREC> hc[NHID >= 3 ? MTC : 1];
-    if (valid) {
+    {
       // ---------------- layer 1 (K = n_in), streamed into layer 2 ---------------
       // Each 32-neuron tile of layer 1 is consumed by layer 2's accumulators as soon
       // as it exists (k-tile by k-tile), so only ONE layer-1 tile is live at a time:
@@ -451,7 +438,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
           for (int s = 0; s < KS1; ++s)
             acc = mfma16(*reinterpret_cast<const u32x4 *>(lds + mt * L1_PER_MT + s * kFragGroupFloats + lo), xhi[s], acc);
         }
-        act16<PREC>(acc);
+        act16(acc);
         return acc;
       };
       if constexpr (NHID == 1) {
@@ -475,7 +462,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         if (next_tile < p.n_tiles) fetch_x(next_tile, xn);
 #pragma unroll
         for (int mt = 0; mt < MTB; ++mt) {
-          act16<PREC>(acc2[mt]);
+          act16(acc2[mt]);
           hb[mt].set(acc2[mt]);
         }
       }
@@ -487,7 +474,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         for (int mt = 0; mt < MTC; ++mt) {
           f32x16 acc = init_acc(lds + B3OFF + 32 * mt, half);
           acc = dense_tile<PREC, MTB>(hb, lds + W1F + W2F + mt * MTB * KTF + lo, acc);
-          act16<PREC>(acc);
+          act16(acc);
           hc[mt].set(acc);
         }
       }
@@ -511,21 +498,14 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     // the smallest register index r of the kept tile with z_r >= best (equivalent to clamp(z_r) == best
     // because best <= +sat; if every class sits below -sat nothing matches and the tile's first class
     // stands for the all-equal tile), by a descending select scan.  The scan used to run in every
-    // class tile (51 ops x 8 tiles; -DNNV_DEFER_ARGMAX=0 restores that for A/B builds).
+    // class tile (51 ops x 8 tiles).
     // The update test is "not (m <= best)" rather than "m > best": identical for ordered values, and a
     // NaN maximum (a row of non-finite soft bits) then ALWAYS parks its tile, whatever v_med3 makes of a
     // NaN, so the deferred scan can never read a slot an earlier row tile left behind: the decoded class
     // of such a row is unspecified but a function of that row alone.
-    f32x16 keep;
     int btile = 0;
     // [wave][q][lane][4 floats]: consecutive lanes write consecutive 16-byte pieces (conflict free)
     float *const keep_slot = keep_base + wave * 1024 + lane * 4;
-    auto scan_first = [&](const f32x16 &acc, float m) -> unsigned {
-      unsigned t = 16u;
-#pragma unroll
-      for (int r = 15; r >= 0; --r) t = acc[r] >= m ? static_cast<unsigned>(r) : t;
-      return t == 16u ? 0u : t;
-    };
     auto argmax_tile = [&](const f32x16 &acc, int mt) {
       float m = __builtin_fmaxf(acc[0], acc[1]);
 #pragma unroll
@@ -533,22 +513,13 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       m = __builtin_amdgcn_fmed3f(m, -kTanhSat, kTanhSat);
       const bool c = !(m <= best);
       best = c ? m : best;
-      if constexpr (KEEP_LDS) {
-        btile = c ? mt : btile;
-        if (c) {  // exec-masked LDS stores: the LDS port, not the vector ALU the fp32 MFMA occupies
+      btile = c ? mt : btile;
+      if (c) {  // exec-masked LDS stores: the LDS port, not the vector ALU the fp32 MFMA occupies
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-            *reinterpret_cast<f32x4 *>(keep_slot + q * 256) = v;
-          }
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          *reinterpret_cast<f32x4 *>(keep_slot + q * 256) = v;
         }
-      } else if constexpr (kDeferArgmax) {
-        btile = c ? mt : btile;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) keep[r] = c ? acc[r] : keep[r];
-      } else {
-        const unsigned t = scan_first(acc, m);
-        bidx = c ? 32 * mt + 4 * half + 8 * static_cast<int>(t >> 2) + static_cast<int>(t & 3u) : bidx;
       }
     };
     // what follows a class tile's MFMAs: debug activations, masking of a ragged class count, argmax
@@ -577,7 +548,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       // two class tiles per iteration: the second tile's MFMAs are independent of the first
       // tile's argmax, so the scheduler can issue them around it (in f16x3 the matrix pipe
       // then works under the argmax VALU stream instead of before it)
-      constexpr int kGroup = NNV_CLASS_GROUP;
+      constexpr int kGroup = kClassGroup;
       for (; mt0 + kGroup - 1 < p.mt_out; mt0 += kGroup) {
         f32x16 accs[kGroup];
 #pragma unroll
@@ -590,7 +561,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       }
     }
     // LDS-resident class tiles (all of them unless this is the stream variant)
-    if (valid) {
+    {
       const int mt_res = STREAM ? p.out_lds_tiles : p.mt_out;
       for (int mt = mt0; mt < mt_res; ++mt) {
         f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
@@ -607,13 +578,13 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     if constexpr (STREAM) {
       // every wave on its own: the fragment groups of the non-resident tiles are ONE linear stream (contiguous in the
       // packed network); a UNIT is what one product block consumes (fp32: one group = 4 k-steps; f16x3: one k-step's
-      // hi + lo groups; f16: one k-step's hi group); NNV_STREAM_DEPTH units in flight, each refilled right after
+      // hi + lo groups; f16: one k-step's hi group); kStreamDepth units in flight, each refilled right after
       // its consumers (same registers: no copies, waits by count)
-      constexpr int D = NNV_STREAM_DEPTH;
+      constexpr int D = kStreamDepth;
       constexpr int UG = PREC == kPrecF16x3 ? 2 : 1;   // groups per unit
       constexpr int UPT = GPT / UG;                    // units per class tile
       static_assert(UPT % D == 0, "prefetch depth must divide the units per class tile");
-      if (valid && p.out_lds_tiles < p.mt_out) {
+      if (p.out_lds_tiles < p.mt_out) {
         const int first = p.out_lds_tiles;
         const int n_groups = (p.mt_out - first) * GPT;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -649,16 +620,18 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         }
       }
     }
-    if constexpr (KEEP_LDS) {
+    {  // the deferred index scan: the kept tile's accumulators back from the lane's LDS slot
+      f32x16 keep;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(keep_slot + q * 256);
 #pragma unroll
         for (int e = 0; e < 4; ++e) keep[4 * q + e] = v[e];
       }
-    }
-    if constexpr (kDeferArgmax) {
-      const unsigned t = scan_first(keep, best);
+      unsigned t = 16u;
+#pragma unroll
+      for (int r = 15; r >= 0; --r) t = keep[r] >= best ? static_cast<unsigned>(r) : t;
+      t = t == 16u ? 0u : t;
       bidx = 32 * btile + 4 * half + 8 * static_cast<int>(t >> 2) + static_cast<int>(t & 3u);
     }
 
@@ -674,8 +647,8 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     // wave (a branch must be wave-uniform) but its result is TAKEN per row: only by rows whose own winner
     // -- in either lane half, because the half merge below compares like with like -- reached the band.
     // decode(row) is a function of the row alone, whatever shares its 32-row tile.
-    if constexpr (kFlatTopPath) {
-      if (valid && __builtin_expect(__builtin_amdgcn_ballot_w64(best >= kFlatBand) != 0, 0)) {
+    {
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(best >= kFlatBand) != 0, 0)) {
         float tb = -__builtin_inff();
         int ti = 0;
         for (int mt = 0; mt < p.mt_out; ++mt) {
@@ -705,7 +678,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       const bool take = (ov > best) || (ov == best && oi < bidx);
       bidx = take ? oi : bidx;
     }
-    if (valid && half == 0 && row < p.n_rows) {
+    if (half == 0 && row < p.n_rows) {
       if (p.cls32) p.cls32[row] = bidx;
       if (!LEAN && p.cls64) p.cls64[row] = bidx;
       if (!LEAN && p.bits) {
@@ -733,11 +706,11 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
     }
     tile = next_tile;
     NNV_STAMP(5);  // epilogue
-#ifdef NNV_DIAG
+#ifdef NNV_DIAG_ON
     ++diag_tiles;
 #endif
   }
-#ifdef NNV_DIAG
+#ifdef NNV_DIAG_ON
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int i = 0; i < 8; ++i) g_diag[i] = diag_sum[i];
     g_diag[8] = diag_tiles;
@@ -807,7 +780,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #if NNV_TU_PREC == 0
 extern const KernelEntry kKernelsF32[] = {
     NNV_FAMILY(kPrecF32, 1), NNV_FAMILY(kPrecF32, 2), NNV_FAMILY(kPrecF32, 3),
-#ifdef NNV_DIAG
+#ifdef NNV_DIAG_ON
     NNV_K(kPrecF32, 2, 3, 4, 2, 1, 256, false),
 #endif
 };
@@ -822,7 +795,7 @@ extern const KernelEntry kKernelsF16x3[] = {
     NNV_K(kPrecF16x3, 4, 2, 4, 2, 1, 768, false), NNV_K(kPrecF16x3, 4, 3, 4, 2, 1, 768, false),
     // single-product f16 mode: same geometry (layer-1 k-steps = ceil(G1 / 2))
     NNV_FAMILY(kPrecF16, 2), NNV_FAMILY(kPrecF16, 4),
-#ifdef NNV_DIAG
+#ifdef NNV_DIAG_ON
     NNV_K(kPrecF16x3, 2, 3, 4, 2, 1, 256, false),
 #endif
 };
@@ -831,7 +804,7 @@ extern const int kNumKernelsF16x3 = sizeof(kKernelsF16x3) / sizeof(kKernelsF16x3
 
 }  // namespace nnv
 
-#if defined(NNV_DIAG) && NNV_TU_PREC == 0
+#if defined(NNV_DIAG_ON) && NNV_TU_PREC == 0
 extern "C" int nnv_debug_read_stamps(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(nnv::g_diag), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
 }

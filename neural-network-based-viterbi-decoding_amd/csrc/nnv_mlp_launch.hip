@@ -4,10 +4,6 @@
 
 #include "nnv_internal.h"
 
-#ifndef NNV_BAND_RESIDENT_DEFAULT
-#define NNV_BAND_RESIDENT_DEFAULT 0   // see decode_configure
-#endif
-
 namespace nnv {
 
 // nnv_mlp_decode.hip compiled with -DNNV_TU_PREC=0 / =1
@@ -43,11 +39,11 @@ const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act, bool lean
 }
 
 // Workgroup size: 1024 threads = 4 waves per SIMD (<= 128 VGPRs) when that
-// instantiation does not spill (more than a handful of registers), else 512 (2 per SIMD).  NNV_THREADS overrides
-// (tuning / A-B runs only).
+// instantiation does not spill (more than a handful of registers), else 512 (2 per SIMD).  (A/B builds only:
+// NNV_THREADS overrides.)
 int pick_threads_impl(const PackedShape &s) {
   static const int forced = [] {
-    const char *e = getenv("NNV_THREADS");
+    const char *e = ab_env("NNV_THREADS");
     const int v = e ? atoi(e) : 0;
     return (v == 256 || v == 512 || v == 768 || v == 1024) ? v : 0;
   }();
@@ -66,7 +62,7 @@ int pick_threads_impl(const PackedShape &s) {
 }
 
 
-int64_t keep_slot_bytes(int threads) { return kKeepLds ? static_cast<int64_t>(threads) * 64 : 0; }
+int64_t keep_slot_bytes(int threads) { return static_cast<int64_t>(threads) * kKeepSlotBytes; }
 
 }  // namespace
 
@@ -93,17 +89,14 @@ int decode_kernel_vgprs(const PackedShape &s, int threads, bool lean) {
 //   stream variant at 1024 threads (every wave streams the class tiles that do not fit): fp32 1.95-1.97 ms, f16x3 0.834-0.844 ms
 //   whole network resident at 512 threads                                              : fp32 1.98-2.01 ms, f16x3 0.893-0.894 ms
 // so the band is STREAMED (earlier in round 4, against round 3's lock-step ring -- 2.04-2.05 / 1.02-1.03 ms -- the
-// resident choice had won).  NNV_BAND_RESIDENT_512=1 / NNV_BAND_STREAM_1024=1 force either (A/B runs only).
+// resident choice had won).  (A/B builds only: NNV_BAND_RESIDENT_512=1 forces the resident choice.)
 int decode_configure(PackedShape *s, int lds_limit) {
-  static const bool band_stream = getenv("NNV_BAND_STREAM_1024") != nullptr;
-  static const bool band_resident = getenv("NNV_BAND_RESIDENT_512") != nullptr;
-  constexpr bool kBandResidentDefault = NNV_BAND_RESIDENT_DEFAULT != 0;
+  static const bool band_resident = ab_env("NNV_BAND_RESIDENT_512") != nullptr;
   const int64_t whole = (s->hid_floats + s->out_floats + s->bias_floats) * 4 + kLdsTailBytes;
   s->streams = 0;
   const int t = pick_threads_impl(*s);
   if (whole + keep_slot_bytes(t) <= lds_limit) return t;
-  const bool resident_512 = band_resident || (kBandResidentDefault && !band_stream);
-  if (resident_512 && t > 512 && whole + keep_slot_bytes(512) <= lds_limit) return 512;
+  if (band_resident && t > 512 && whole + keep_slot_bytes(512) <= lds_limit) return 512;
   s->streams = 1;
   // streamed: hidden layers + biases + winner slots must fit; a network with a very large class layer's biases
   // (4096 classes: 16 KB) falls back to 512 threads (half the winner slots)
@@ -125,8 +118,8 @@ nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
   const int64_t per_tile_bytes = static_cast<int64_t>(class_tile_kb(s.precision, s.kt_out)) * 1024;
   int64_t fit = (lds_limit - kLdsTailBytes - scratch - base_floats * 4) / per_tile_bytes;
   if (fit > s.mt_out) fit = s.mt_out;
-  if (s.streams) {  // A/B runs only: cap the resident class tiles of the stream variant
-    static const int cap = [] { const char *e = getenv("NNV_STREAM_MAX_RESIDENT"); return e ? atoi(e) : -1; }();
+  if (s.streams) {  // A/B builds only: cap the resident class tiles of the stream variant
+    static const int cap = [] { const char *e = ab_env("NNV_STREAM_MAX_RESIDENT"); return e ? atoi(e) : -1; }();
     if (cap >= 0 && fit > cap) fit = cap;
   }
   if (s.streams == 0 && fit < s.mt_out) return NNV_ERR_UNSUPPORTED_SHAPE;  // decode_configure sized it
@@ -186,7 +179,7 @@ nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
                          const LaunchPlan &plan, bool write_act, int device,
                          hipStream_t stream) {
   const int nt = write_act ? 512 : plan.threads;
-  static const bool no_lean = getenv("NNV_NO_LEAN") != nullptr;  // A/B runs only
+  static const bool no_lean = ab_env("NNV_NO_LEAN") != nullptr;  // A/B builds only
   const bool lean = !no_lean && s.streams == 0 && !write_act && p.xvec && p.n_bins == 1 && !p.bits && !p.cls64 &&
                     p.n_classes % 32 == 0;
   const KernelEntry *k = find_kernel(s, nt, write_act, lean);

@@ -25,6 +25,7 @@ struct nnv_wide_handle {
   int32_t fused;                      // 1: fused_dev holds the fragment-order packing
   int32_t num_cus;
   float *fused_dev;
+  int32_t path;                       // nnv_wide_path: AUTO (= K6 whenever packed), or what nnv_wide_set_path pinned
   nnv::WideFusedParams fp;            // static part (pointers into fused_dev, shapes); per-call fields filled at launch
 };
 
@@ -129,12 +130,18 @@ nnv_status pack_fused(const nnv_wide_desc *net, nnv_wide_handle *h) {
         host[hw_off + static_cast<int64_t>(c) * fp.head_quads * 4 + k] = net->W_host[nh][static_cast<size_t>(k) * C + c];
     for (int c = 0; c < C; ++c) host[hb_off + c] = net->b_host[nh][c];
   }
-  if (hipMalloc(reinterpret_cast<void **>(&h->fused_dev), host.size() * sizeof(float)) != hipSuccess)
-    return NNV_ERR_OUT_OF_MEMORY;
+  // K6 is an OPTION on top of a handle the layered path already serves (as K4c / K4d are for the bank): if its
+  // second copy of the weights cannot be allocated or uploaded the handle stays on the layered path
+  if (hipMalloc(reinterpret_cast<void **>(&h->fused_dev), host.size() * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();   // clear the sticky error: this is not a failure of the call
+    h->fused_dev = nullptr;
+    return NNV_OK;
+  }
   if (hipMemcpy(h->fused_dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
     (void)hipFree(h->fused_dev);
     h->fused_dev = nullptr;
-    return NNV_ERR_HIP;
+    return NNV_OK;
   }
   for (int l = 0; l < nm; ++l) {
     fp.w[l] = h->fused_dev + w_off[l];
@@ -147,9 +154,10 @@ nnv_status pack_fused(const nnv_wide_desc *net, nnv_wide_handle *h) {
   {
     const nnv_status e = nnv::wide_fused_prepare(fp, h->act, h->device);
     if (e != NNV_OK) {
+      (void)hipGetLastError();
       (void)hipFree(h->fused_dev);
       h->fused_dev = nullptr;
-      return e;
+      return NNV_OK;
     }
   }
   h->fused = 1;
@@ -241,12 +249,8 @@ int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out) {
     return NNV_ERR_HIP;
   }
   h->num_cus = prop.multiProcessorCount;
-  const nnv_status fs = pack_fused(net, h);
-  if (fs != NNV_OK) {
-    (void)hipFree(h->dev);
-    delete h;
-    return fs;
-  }
+  h->path = NNV_WIDE_PATH_AUTO;
+  (void)pack_fused(net, h);   // optional: on any failure h->fused stays 0 and the layered path serves the handle
   *out = h;
   return NNV_OK;
 }
@@ -257,6 +261,20 @@ int32_t nnv_wide_free(nnv_wide_handle *h) {
   const hipError_t e2 = h->fused_dev ? hipFree(h->fused_dev) : hipSuccess;
   delete h;
   return (e == hipSuccess && e2 == hipSuccess) ? NNV_OK : NNV_ERR_HIP;
+}
+
+int32_t nnv_wide_set_path(nnv_wide_handle *h, int32_t path) {
+  if (!h) return NNV_ERR_INVALID_ARGUMENT;
+  if (path != NNV_WIDE_PATH_AUTO && path != NNV_WIDE_PATH_FUSED && path != NNV_WIDE_PATH_LAYERED)
+    return NNV_ERR_INVALID_ARGUMENT;
+  if (path == NNV_WIDE_PATH_FUSED && !h->fused) return NNV_ERR_UNSUPPORTED_SHAPE;
+  h->path = path;
+  return NNV_OK;
+}
+
+int32_t nnv_wide_get_path(const nnv_wide_handle *h) {
+  if (!h) return -NNV_ERR_INVALID_ARGUMENT;
+  return (h->fused && h->path != NNV_WIDE_PATH_LAYERED) ? NNV_WIDE_PATH_FUSED : NNV_WIDE_PATH_LAYERED;
 }
 
 int64_t nnv_wide_workspace_bytes(const nnv_wide_handle *h, int64_t chunk_rows) {
@@ -280,22 +298,19 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev, int64_
   int64_t chunk = workspace_bytes / per_row / 128 * 128;
   if (chunk < 128) return NNV_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // K6: one persistent launch for the whole chain (no workspace traffic).  NNV_WIDE_FUSED=0 keeps the
-  // layer-at-a-time path (A/B runs, and the tests that hold the two paths against each other).
-  if (h->fused) {
-    const char *e = getenv("NNV_WIDE_FUSED");
-    if (!(e && e[0] == '0')) {
-      nnv::WideFusedParams fp = h->fp;
-      fp.x = x_dev;
-      fp.row_stride = row_stride;
-      fp.n_rows = n_rows;
-      fp.n_units = (n_rows + 31) / 32;
-      fp.x16 = (row_stride % 4 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 16 == 0) ? 1 : 0;
-      fp.cls32 = cls32_dev;
-      fp.cls64 = cls64_dev;
-      fp.act = act_dev;
-      return nnv::wide_fused_launch(fp, h->act, h->num_cus, h->device, s);
-    }
+  // K6: one persistent launch for the whole chain (no workspace traffic), unless nnv_wide_set_path pinned the
+  // handle to the layer-at-a-time path (parity tests hold the two against each other)
+  if (nnv_wide_get_path(h) == NNV_WIDE_PATH_FUSED) {
+    nnv::WideFusedParams fp = h->fp;
+    fp.x = x_dev;
+    fp.row_stride = row_stride;
+    fp.n_rows = n_rows;
+    fp.n_units = (n_rows + 31) / 32;
+    fp.x16 = (row_stride % 4 == 0 && reinterpret_cast<uintptr_t>(x_dev) % 16 == 0) ? 1 : 0;
+    fp.cls32 = cls32_dev;
+    fp.cls64 = cls64_dev;
+    fp.act = act_dev;
+    return nnv::wide_fused_launch(fp, h->act, h->num_cus, h->device, s);
   }
   float *buf[2] = {static_cast<float *>(workspace_dev),
                    static_cast<float *>(workspace_dev) + chunk * h->max_mpad};

@@ -49,10 +49,7 @@ constexpr int kRows = kFusedRows;        // rows per workgroup step (two 32-row 
 // CU, whose hand-overs (barriers, first loads, the argmax pass) then run under each other's MFMAs: a 64-row step of
 // a narrow network is mostly such latencies (14-200-96-48-128: 24 k MFMA cycles per SIMD against ~20 k of them;
 // measured 2.32 -> 1.95 ms per 2 M rows, 16-256-128-64-256 2.94 -> 2.53 ms).
-#ifndef NNV_FUSED_PREFETCH
-#define NNV_FUSED_PREFETCH 4
-#endif
-constexpr int kPrefetch = NNV_FUSED_PREFETCH;  // weight fragment groups in flight per wave (A/B builds: 2, 8)
+constexpr int kPrefetch = 4;  // weight fragment groups in flight per wave (measured 2 / 4 / 8: 4 is the fastest)
 
 __device__ __forceinline__ float fused_tanh_f32(float z) {  // == dense_tanh_f32 (nnv_dense.hip)
   const float e = __builtin_amdgcn_exp2f(z * 2.8853900817779268f);
@@ -106,11 +103,7 @@ __global__ __launch_bounds__(64 * WAVES) void wide_fused_kernel(const WideFusedP
   // workgroup cost 62; in units it is 61.5.
   const int64_t u_begin = p.n_units * blockIdx.x / gridDim.x;
   const int64_t u_end = p.n_units * (static_cast<int64_t>(blockIdx.x) + 1) / gridDim.x;
-#ifdef NNV_FUSED_FORCE_HALF   // timing experiment only: every step ONE row tile = 4 MFMAs per weight fragment (16 B/cycle/CU from L2)
-  constexpr int kUnitStep = 1;
-#else
   constexpr int kUnitStep = 2;
-#endif
   for (int64_t u = u_begin; u < u_end; u += kUnitStep) {
     const int64_t row0 = u * 32;
     const bool two = kUnitStep == 2 && u + 1 < u_end;   // workgroup-uniform
@@ -325,10 +318,10 @@ int64_t wide_fused_lds_bytes(const WideFusedParams &p) {
 }
 
 // W waves x (16 / W) workgroups per CU, W the smallest of 4, 8, 16 with: every layer has at most W neuron tiles and
-// one workgroup's LDS is at most 160 KB / (16 / W).  NNV_FUSED_WAVES=16 (or 8) sets a floor (A/B runs).
+// one workgroup's LDS is at most 160 KB / (16 / W).  (A/B builds only: NNV_FUSED_WAVES=16 or 8 sets a floor.)
 int wide_fused_pick_waves(const WideFusedParams &p) {
   static const int floor_w = [] {
-    const char *e = getenv("NNV_FUSED_WAVES");
+    const char *e = ab_env("NNV_FUSED_WAVES");
     const int v = e ? atoi(e) : 0;
     return (v == 4 || v == 8 || v == 16) ? v : 4;
   }();

@@ -343,6 +343,18 @@ class WideMLP:
         except Exception:
             pass
 
+    def set_path(self, path: str) -> None:
+        """Pin the handle to one kernel: "fused" (K6, the whole chain in one persistent launch), "layered" (one GEMM
+        launch per layer) or "auto" (K6 whenever the shape allows it, the default).  For parity tests and A/B
+        timing; "fused" on a shape K6 does not take raises."""
+        _cabi.check(self._lib.nnv_wide_set_path(self._handle, _cabi.NNV_WIDE_PATH[path]), "nnv_wide_set_path")
+
+    @property
+    def path(self) -> str:
+        """The kernel ``decode`` runs on this handle: "fused" or "layered"."""
+        v = int(self._lib.nnv_wide_get_path(self._handle))
+        return {1: "fused", 2: "layered"}[v]
+
     def _run(self, x: torch.Tensor, n_rows: int, row_stride: int, want_act: bool, want_cls64: bool):
         cls32 = torch.empty(n_rows, dtype=torch.int32, device=self.device)
         cls64 = torch.empty(n_rows, dtype=torch.int64, device=self.device) if want_cls64 else None
@@ -426,6 +438,18 @@ class BitwiseBank:
             self.close()
         except Exception:
             pass
+
+    def set_path(self, path: str) -> None:
+        """Pin the handle to one kernel: "tiled" (K4b, the LDS-tiled GEMM), "stream" (K4c: rows resident in LDS, first
+        layers streamed from L2; fp32 banks of >= 2 positions), "single" (K4d: one HBM-streaming launch per
+        position; banks of <= 2 positions) or "auto" (by size, the default).  A path whose packing the handle does
+        not hold raises."""
+        _cabi.check(self._lib.nnv_bitwise_set_path(self._handle, _cabi.NNV_BITWISE_PATH[path]), "nnv_bitwise_set_path")
+
+    def path_for(self, x: torch.Tensor) -> str:
+        """The kernel ``decode(x)`` runs: "tiled", "stream" or "single" (K4d needs 16-byte aligned rows)."""
+        v = int(self._lib.nnv_bitwise_path_for(self._handle, _ptr(x)))
+        return {1: "tiled", 2: "stream", 3: "single"}[v]
 
     def decode(self, x: torch.Tensor, labels: Optional[torch.Tensor] = None, want_act: bool = False,
                errors: Optional[torch.Tensor] = None):

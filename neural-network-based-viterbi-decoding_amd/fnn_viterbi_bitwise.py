@@ -247,7 +247,8 @@ def train_and_evaluate(config: BitwiseDecoderConfig, train_info: np.ndarray, tra
     bit = torch.as_tensor(np.asarray(train_info)[:, config.bit_position].astype(np.int64), device=dev)
     y_all = torch.nn.functional.one_hot(bit, 2).to(torch.float32)
     params = list(W.values()) + list(B.values())
-    opt = torch.optim.Adam(params, lr=config.learning_rate, capturable=(dev.type == "cuda"))
+    from .training import GraphedStep, TFAdam
+    opt = TFAdam(params, lr=config.learning_rate)     # tf.train.AdamOptimizer (src/fnn_viterbi_bitwise.py:451), TF-1's update rule
     bs = int(config.batch_size)
     total_batch = int(config.training_size / bs)
 
@@ -261,7 +262,6 @@ def train_and_evaluate(config: BitwiseDecoderConfig, train_info: np.ndarray, tra
         opt.step()
         return cost.detach()
 
-    from .training import GraphedStep
     run = GraphedStep(step, params, opt, [x_all[:bs], y_all[:bs]]) if total_batch > 0 else step
     for epoch in range(int(config.training_epochs)):
         avg_cost = torch.zeros((), device=dev)

@@ -259,7 +259,8 @@ def _train(config: SequentialDecoderConfig, train_info, train_coded, weights, bi
     B = [torch.tensor(biases[k], dtype=torch.float32, device=dev, requires_grad=True) for k in _B_KEYS]
     stream = torch.as_tensor(np.asarray(train_coded)[0].astype(np.float32), device=dev)
     bits = torch.as_tensor(np.asarray(train_info)[0].astype(np.int64), device=dev)
-    opt = torch.optim.Adam(W + B, lr=config.learning_rate, capturable=(dev.type == "cuda"))
+    from .training import GraphedStep, TFAdam
+    opt = TFAdam(W + B, lr=config.learning_rate)      # tf.train.AdamOptimizer (src/fnn_viterbi_seq_predict.py:488), TF-1's update rule
     bs, win = int(config.batch_size), int(config.window_length)
     total_batch = int(config.total_training_instances / bs)
     windows = stream.unfold(0, win, 2)                      # window i = stream[2i : 2i + win]
@@ -277,7 +278,6 @@ def _train(config: SequentialDecoderConfig, train_info, train_coded, weights, bi
         opt.step()
         return cost.detach()
 
-    from .training import GraphedStep
     run = GraphedStep(step, W + B, opt, [windows[:bs], bits[:bs]]) if total_batch > 0 else step
     for epoch in range(int(config.training_epochs)):
         avg_cost = torch.zeros((), device=dev)

@@ -249,8 +249,8 @@ def train_seq2seq(config: RNNDecoderConfig, train_info: np.ndarray, train_encode
     dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     P = {k: torch.tensor(v, dtype=torch.float32, device=dev, requires_grad=True)
          for k, v in model["params"].items()}
-    opt = torch.optim.Adam(list(P.values()), lr=config.learning_rate, betas=(0.9, 0.999), eps=1e-8,
-                           capturable=(dev.type == "cuda"))
+    from .training import GraphedStep, TFAdam
+    opt = TFAdam(list(P.values()), lr=config.learning_rate)   # tf.train.AdamOptimizer (src/rnn_viterbi.py:316), TF-1's update rule
     batches_per_epoch = int(config.training_size / config.batch_size)
     max_batches = batches_per_epoch * config.training_epochs
     loss_history = []
@@ -270,7 +270,6 @@ def train_seq2seq(config: RNNDecoderConfig, train_info: np.ndarray, train_encode
                 torch.as_tensor(np.asarray(f["decoder_targets"], np.float32), device=dev))
 
     # one batch step = 4L cell evaluations = thousands of tiny kernels: captured once, replayed per batch
-    from .training import GraphedStep
     run = GraphedStep(step, list(P.values()), opt, feeds_of(0), verbose) if max_batches > 0 else step
     if verbose:
         print(f"Training for {config.training_epochs} epochs ({max_batches} batches)...")

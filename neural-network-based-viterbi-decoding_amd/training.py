@@ -7,16 +7,18 @@ Restates the optimisation the reference builds in TensorFlow
     last op is tanh, and that tensor is passed as ``logits``)
     + beta * (l2(h1) + l2(h2) + l2(h3)), with tf.nn.l2_loss(w) = sum(w^2)/2;
     the output layer's weights are not regularised;
-  * Adam, learning rate from the config, TF defaults otherwise.  torch.optim.Adam places eps as
-    lr_t * m_hat / (sqrt(v_hat) + eps); TF-1 AdamOptimizer uses lr * sqrt(1-b2^t)/(1-b1^t) * m /
-    (sqrt(v) + eps), i.e. eps OUTSIDE the bias correction ("epsilon hat"): the two differ by a factor
-    sqrt(1-b2^t) on eps (1e-8), far below anything the decoded bits can see, so this is a restatement
-    of the recipe, not a bit-identical optimiser (and nothing of the reference's training can be
-    pinned anyway: no TensorFlow here);
+  * tf.train.AdamOptimizer, learning rate from the config, TF-1 defaults otherwise, with TF-1's
+    update rule (:class:`TFAdam`): lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), var -= lr_t m / (sqrt(v) + eps),
+    i.e. eps OUTSIDE the bias correction -- not torch.optim.Adam's placement;
   * contiguous, unshuffled, class-major mini-batches; the remainder that does
     not fill a batch is dropped (``int(num_training_samples / batch_size)``);
-  * optional dropout after each hidden tanh (mixed_snr:596-627), evaluation
-    always without dropout (:715-720).
+  * optional dropout after each hidden tanh (mixed_snr:596-627: tf.nn.dropout = x * mask / keep_prob),
+    evaluation always without dropout (:715-720).
+
+One step (loss, its eight gradients, the Adam update) is checked against a float64 numpy restatement of the
+same lines (oracle/train_oracle.py) in tests/test_trainer.py, on the CPU and on the GPU, eager and as the
+captured HIP graph.  TensorFlow itself is not installable here: the restatement is pinned to the reference's
+text, not to its outputs.
 
 Training is not the hot path of this project: it is plain PyTorch autograd
 (on the GPU when there is one).  Decoding with the trained weights goes
@@ -25,7 +27,7 @@ through the HIP kernel.
 from __future__ import annotations
 
 import os
-from typing import Dict, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -41,8 +43,8 @@ class GraphedStep:
     by its kernel launches (the feed-forward trainer: ~25 per step; the recurrent one: thousands).
     Same kernels in the same order as eager mode; on the CPU, or if capture fails, calls run eagerly.
 
-    ``params``: the leaf tensors the optimizer updates; ``opt`` must have been built with
-    ``capturable=True`` on CUDA; ``example_inputs``: tensors of the batch shapes (copied)."""
+    ``params``: the leaf tensors the optimizer updates; ``opt``: a :class:`TFAdam` (or a torch optimizer built
+    with ``capturable=True``); ``example_inputs``: tensors of the batch shapes (copied)."""
 
     def __init__(self, step, params, opt, example_inputs, verbose: bool = False):
         self._step = step
@@ -53,15 +55,20 @@ class GraphedStep:
         if dev.type != "cuda" or os.environ.get("NNV_NO_TRAIN_GRAPH"):   # the switch is for A/B tests
             return
         saved = [t.detach().clone() for t in params]
+        opt_state = list(opt.state_tensors()) if hasattr(opt, "state_tensors") else []
+        saved_state = [t.detach().clone() for t in opt_state]
 
         def restore():                                   # undo warm-up steps: weights and optimizer state
             with torch.no_grad():
                 for t, v in zip(params, saved):
                     t.copy_(v)
-                for st in opt.state.values():
-                    for v in st.values():
-                        if torch.is_tensor(v):
-                            v.zero_()
+                for t, v in zip(opt_state, saved_state):  # TFAdam: moments AND the running beta powers
+                    t.copy_(v)
+                if not opt_state:                         # a torch optimizer: its (lazily created) state starts at zero
+                    for st in opt.state.values():
+                        for v in st.values():
+                            if torch.is_tensor(v):
+                                v.zero_()
 
         try:
             static = [t.clone() for t in example_inputs]
@@ -99,46 +106,127 @@ class GraphedStep:
         return self._cost
 
 
+class TFAdam:
+    """``tf.train.AdamOptimizer`` of TensorFlow 1.x (the optimiser every script of the reference uses:
+    src/fnn_viterbi.py:561-563, mixed_snr:734-738, bitwise / seq_predict / rnn alike) on a list of leaf tensors:
+
+        t <- t + 1;  lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+        m <- m + (g - m) (1 - beta1);   v <- v + (g^2 - v) (1 - beta2)
+        var <- var - lr_t * m / (sqrt(v) + epsilon)
+
+    epsilon sits OUTSIDE the bias correction ("epsilon hat"), unlike torch.optim.Adam.  The powers beta^t are
+    running float32 products held on the device (as TF keeps them in ``beta1_power`` / ``beta2_power``), so a step is
+    pure tensor arithmetic: capturable into a HIP graph, no host value changes between replays."""
+
+    def __init__(self, params: Sequence[torch.Tensor], lr: float, beta1: float = 0.9, beta2: float = 0.999,
+                 eps: float = 1e-8):
+        self.params = list(params)
+        self.lr, self.beta1, self.beta2, self.eps = float(lr), float(beta1), float(beta2), float(eps)
+        dev = self.params[0].device
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.beta1_power = torch.ones((), dtype=torch.float32, device=dev)
+        self.beta2_power = torch.ones((), dtype=torch.float32, device=dev)
+
+    def state_tensors(self) -> List[torch.Tensor]:
+        return self.m + self.v + [self.beta1_power, self.beta2_power]
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        for p in self.params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self) -> None:
+        grads = [p.grad for p in self.params]
+        self.beta1_power.mul_(self.beta1)
+        self.beta2_power.mul_(self.beta2)
+        lr_t = self.lr * torch.sqrt(1.0 - self.beta2_power) / (1.0 - self.beta1_power)
+        torch._foreach_lerp_(self.m, grads, 1.0 - self.beta1)                 # m += (g - m)(1 - beta1)
+        torch._foreach_lerp_(self.v, torch._foreach_mul(grads, grads), 1.0 - self.beta2)
+        denom = torch._foreach_sqrt(self.v)
+        torch._foreach_add_(denom, self.eps)
+        upd = torch._foreach_div(self.m, denom)
+        torch._foreach_mul_(upd, lr_t)
+        torch._foreach_sub_(self.params, upd)
+
+
+class FNNTrainer:
+    """The reference's training step for the feed-forward decoder as an object (the lines cited in the module
+    docstring).  ``weights`` / ``biases``: dictionaries keyed like the reference's (``h1..h3, out`` / ``b1..b3, out``).
+
+    ``step(xb, yb)`` = what ``sess.run([optimizer, cost], feed_dict)`` does (src/fnn_viterbi.py:589-592): returns the
+    cost of the batch BEFORE the update and applies the update.  ``masks`` (one 0/1 tensor [B, width] per hidden layer)
+    fixes the dropout pattern for tests; without them a fresh Bernoulli(keep_prob) mask is drawn per call."""
+
+    def __init__(self, weights: Dict[str, np.ndarray], biases: Dict[str, np.ndarray], learning_rate: float,
+                 beta_regularization: float, use_dropout: bool = False, keep_prob: float = 0.5, device=None):
+        self.device = _device() if device is None else torch.device(device)
+        self.w_keys = [k for k in ("h1", "h2", "h3") if k in weights] + ["out"]
+        self.b_keys = [k for k in ("b1", "b2", "b3") if k in biases] + ["out"]
+        mk = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=self.device, requires_grad=True)
+        self.W = [mk(weights[k]) for k in self.w_keys]
+        self.B = [mk(biases[k]) for k in self.b_keys]
+        self.beta = float(beta_regularization)
+        self.use_dropout, self.keep_prob = bool(use_dropout), float(keep_prob)
+        self.n_hidden = len(self.W) - 1
+        self.opt = TFAdam(self.W + self.B, lr=learning_rate)
+
+    def parameters(self) -> List[torch.Tensor]:
+        return self.W + self.B
+
+    def forward(self, xb: torch.Tensor, train: bool, masks: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+        h = xb
+        for i in range(self.n_hidden):
+            h = torch.tanh(h @ self.W[i] + self.B[i])
+            if masks is not None:
+                h = h * (masks[i] / self.keep_prob)
+            elif train and self.use_dropout:                     # tf.nn.dropout: x * floor(keep_prob + U) / keep_prob
+                h = h * ((torch.rand_like(h) < self.keep_prob).to(h.dtype) / self.keep_prob)
+        return torch.tanh(h @ self.W[-1] + self.B[-1])
+
+    def cost(self, xb: torch.Tensor, yb: torch.Tensor, masks: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+        pred = self.forward(xb, True, masks)
+        ce = -(yb * torch.log_softmax(pred, dim=1)).sum(dim=1).mean()
+        reg = sum(0.5 * (w * w).sum() for w in self.W[:self.n_hidden])
+        return ce + self.beta * reg
+
+    def gradients(self, xb, yb, masks=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+        """(cost, [dW..., db...]) without touching the weights (parity tests)."""
+        self.opt.zero_grad(set_to_none=False)
+        c = self.cost(xb, yb, masks)
+        c.backward()
+        return c.detach(), [p.grad.detach().clone() for p in self.parameters()]
+
+    def step(self, xb: torch.Tensor, yb: torch.Tensor, masks: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+        c = self.cost(xb, yb, masks)
+        self.opt.zero_grad(set_to_none=False)
+        c.backward()
+        self.opt.step()
+        return c.detach()
+
+    def export(self) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
+        return ({k: w.detach().cpu().numpy().copy() for k, w in zip(self.w_keys, self.W)},
+                {k: b.detach().cpu().numpy().copy() for k, b in zip(self.b_keys, self.B)})
+
+
 def train_network(config, training_set: np.ndarray, training_labels: np.ndarray,
                   weights: Dict[str, np.ndarray], biases: Dict[str, np.ndarray],
                   use_dropout: bool = False, keep_prob: float = 0.5,
                   verbose: bool = True) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
     """Returns trained copies of (weights, biases), keyed like the inputs."""
-    dev = _device()
-    w_keys = [k for k in ("h1", "h2", "h3") if k in weights] + ["out"]
-    b_keys = [k for k in ("b1", "b2", "b3") if k in biases] + ["out"]
-    W = [torch.tensor(np.asarray(weights[k]), dtype=torch.float32, device=dev, requires_grad=True)
-         for k in w_keys]
-    B = [torch.tensor(np.asarray(biases[k]), dtype=torch.float32, device=dev, requires_grad=True)
-         for k in b_keys]
+    tr = FNNTrainer(weights, biases, config.learning_rate, config.beta_regularization,
+                    use_dropout=use_dropout, keep_prob=keep_prob)
+    dev = tr.device
     x_all = torch.as_tensor(np.asarray(training_set), dtype=torch.float32, device=dev)
     y_all = torch.as_tensor(np.asarray(training_labels), dtype=torch.float32, device=dev)
-    opt = torch.optim.Adam(W + B, lr=config.learning_rate, betas=(0.9, 0.999), eps=1e-8,
-                           capturable=(dev.type == "cuda"))
     bs = int(config.batch_size)
     total_batch = int(config.num_training_samples / bs)
-    beta = float(config.beta_regularization)
-    n_hidden = len(W) - 1
-
-    def model(xb, train: bool):
-        h = xb
-        for i in range(n_hidden):
-            h = torch.tanh(h @ W[i] + B[i])
-            if train and use_dropout:
-                h = torch.nn.functional.dropout(h, p=1.0 - keep_prob, training=True)
-        return torch.tanh(h @ W[-1] + B[-1])
-
-    def step(xb, yb):
-        pred = model(xb, True)
-        ce = -(yb * torch.log_softmax(pred, dim=1)).sum(dim=1).mean()
-        reg = sum(0.5 * (w * w).sum() for w in W[:n_hidden])
-        cost = ce + beta * reg
-        opt.zero_grad(set_to_none=False)
-        cost.backward()
-        opt.step()
-        return cost.detach()
-
-    run = GraphedStep(step, W + B, opt, [x_all[:bs], y_all[:bs]], verbose) if total_batch > 0 else step
+    step = lambda xb, yb: tr.step(xb, yb)
+    run = GraphedStep(step, tr.parameters(), tr.opt, [x_all[:bs], y_all[:bs]], verbose) if total_batch > 0 else step
 
     for epoch in range(int(config.training_epochs)):
         avg_cost = torch.zeros((), device=dev)
@@ -147,6 +235,4 @@ def train_network(config, training_set: np.ndarray, training_labels: np.ndarray,
         if verbose and epoch % int(getattr(config, "display_step", 1)) == 0:
             print(f"Epoch: {epoch + 1:04d} | cost = {float(avg_cost):.9f}")
 
-    new_w = {k: w.detach().cpu().numpy().copy() for k, w in zip(w_keys, W)}
-    new_b = {k: b.detach().cpu().numpy().copy() for k, b in zip(b_keys, B)}
-    return new_w, new_b
+    return tr.export()

@@ -103,9 +103,9 @@ def test_bank_argument_validation(cuda_device):
 
 @pytest.mark.parametrize("block_length,n_pos,n_rows", [(512, 40, 1500), (24, 24, 777), (25, 17, 129), (40, 3, 1),
                                                        (100, 33, 4099)])
-def test_streamed_bank_equals_the_tiled_bank_bit_for_bit(cuda_device, monkeypatch, block_length, n_pos, n_rows):
+def test_streamed_bank_equals_the_tiled_bank_bit_for_bit(cuda_device, block_length, n_pos, n_rows):
     """K4c (rows resident in LDS, every position's first layer streamed from L2; the fp32 bank's default from 33
-    positions on since round 4) against K4b (LDS-tiled GEMM, NNV_BANK_STREAM=0, read per call): the same k order in the first layer and the same
+    positions on since round 4) against K4b (LDS-tiled GEMM; BitwiseBank.set_path pins either): the same k order in the first layer and the same
     sequential 32-term head chain, so decided bits, ReLU'd outputs and error counters are IDENTICAL, not just close."""
     cfg = bw.BitwiseDecoderConfig(block_length=block_length, training_size=4, test_size=n_rows, test_snr_index=3)
     np.random.seed(3 * block_length + n_pos)
@@ -114,19 +114,22 @@ def test_streamed_bank_equals_the_tiled_bank_bit_for_bit(cuda_device, monkeypatc
     x = torch.from_numpy(enc.astype(np.float32)).cuda()
     labels = torch.from_numpy(np.ascontiguousarray(np.resize(info.T, (n_pos, n_rows)).astype(np.uint8))).cuda()
     bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models], precision="f32")
-    monkeypatch.delenv("NNV_BANK_STREAM", raising=False)
-    monkeypatch.setenv("NNV_BANK_STREAM_MIN", "2")     # K4c whatever the bank's size (default: from 33 positions on)
-    monkeypatch.setenv("NNV_BANK_SINGLE", "0")         # ... and no per-position launches for the smallest banks
+    assert bank.path_for(x) == ("stream" if n_pos >= 33 else "tiled")    # the default: K4c from 33 positions on
+    bank.set_path("stream")                            # K4c whatever the bank's size
+    assert bank.path_for(x) == "stream"
     a = bank.decode(x, labels=labels, want_act=True)
-    monkeypatch.setenv("NNV_BANK_STREAM", "0")
+    bank.set_path("tiled")
+    assert bank.path_for(x) == "tiled"
     b = bank.decode(x, labels=labels, want_act=True)
-    monkeypatch.delenv("NNV_BANK_STREAM", raising=False)
+    bank.set_path("stream")
     assert torch.equal(a["bits"], b["bits"]) and torch.equal(a["act"], b["act"]) and torch.equal(a["errors"], b["errors"])
     # and a view of x that starts 8 bytes into an allocation (rows 8-byte aligned only)
     if enc.shape[1] % 4 == 2:
         pad = torch.empty(x.numel() + 2, dtype=torch.float32, device="cuda")
         pad[2:] = x.reshape(-1)
-        c = bank.decode(pad[2:].view_as(x), labels=labels, want_act=True)
+        view = pad[2:].view_as(x)
+        assert bank.path_for(view) == "stream"
+        c = bank.decode(view, labels=labels, want_act=True)
         assert torch.equal(c["bits"], a["bits"]) and torch.equal(c["act"], a["act"])
     bank.close()
 
@@ -145,29 +148,28 @@ def _bank_inputs(block_length, n_pos, n_rows, seed):
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])   # f16x3: steps of 16 inputs, hi / lo planes split in registers
 @pytest.mark.parametrize("block_length,n_pos,n_rows", [(512, 1, 9001), (512, 2, 1500), (200, 1, 4099), (26, 2, 31),
                                                        (66, 1, 257), (570, 1, 640), (512, 1, 1), (28, 1, 100)])
-def test_single_position_kernel_against_the_oracle_and_the_tiled_path(cuda_device, monkeypatch, block_length, n_pos, n_rows,
+def test_single_position_kernel_against_the_oracle_and_the_tiled_path(cuda_device, block_length, n_pos, n_rows,
                                                                       precision):
     """K4d (round 4; banks of up to 2 positions, 16-byte aligned rows): rows straight from HBM into the MFMA B operand,
     the contraction split over the 16 waves, partial sums meeting in LDS.  Per position against float64 and the C
-    restatement; against K4b (NNV_BANK_SINGLE=0) the outputs agree to rounding -- the summation ORDER differs (16
+    restatement; against K4b (set_path) the outputs agree to rounding -- the summation ORDER differs (16
     slice sums instead of one chain), so not bit for bit -- and the decided bits wherever the float64 margin is not a tie;
     counters are exact functions of the bits; a second launch returns the same bytes."""
     cfg, x_np, models, labels_np = _bank_inputs(block_length, n_pos, n_rows, seed=11 * block_length + n_pos)
     x = torch.from_numpy(x_np).cuda()
     labels = torch.from_numpy(labels_np).cuda()
     bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models], precision=precision)
-    monkeypatch.delenv("NNV_BANK_SINGLE", raising=False)
+    k4d_expected = n_pos == 1 or precision == "f32"          # f16x3: a single position only
+    assert bank.path_for(x) == ("single" if k4d_expected else "tiled")   # the dispatch itself, not inferred from bytes
     a = bank.decode(x, labels=labels, want_act=True)
     a2 = bank.decode(x, labels=labels, want_act=True)
     assert torch.equal(a["bits"], a2["bits"]) and torch.equal(a["act"], a2["act"]) and torch.equal(a["errors"], a2["errors"])
-    monkeypatch.setenv("NNV_BANK_SINGLE", "0")
+    bank.set_path("tiled")
+    assert bank.path_for(x) == "tiled"
     t = bank.decode(x, labels=labels, want_act=True)
-    monkeypatch.delenv("NNV_BANK_SINGLE", raising=False)
+    bank.set_path("auto")
     bits, act = a["bits"].cpu().numpy(), a["act"].cpu().numpy()
     t_bits, t_act = t["bits"].cpu().numpy(), t["act"].cpu().numpy()
-    k4d_expected = n_pos == 1 or precision == "f32"          # f16x3: a single position only
-    assert not k4d_expected or not torch.equal(a["act"], t["act"]) or n_rows < 64 or block_length < 100, \
-        "K4d did not run (same bytes as K4b)"
     assert np.abs(act - t_act).max() < 2e-5 * max(1.0, np.abs(t_act).max())
     for p, (w, b) in enumerate(models):
         _check_position(bits[p].astype(np.int64), act[p], x_np, w, b)
@@ -181,6 +183,7 @@ def test_single_position_kernel_against_the_oracle_and_the_tiled_path(cuda_devic
     # served -- by the tiled path, whose bytes are known
     pad = torch.empty(x.numel() + 2, dtype=torch.float32, device="cuda")
     pad[2:] = x.reshape(-1)
+    assert bank.path_for(pad[2:].view_as(x)) == "tiled"
     u = bank.decode(pad[2:].view_as(x), labels=labels, want_act=True)
     assert torch.equal(u["bits"], t["bits"]) and torch.equal(u["act"], t["act"]) and torch.equal(u["errors"], t["errors"])
     bank.close()
@@ -218,6 +221,7 @@ def test_bank_decode_is_hip_graph_capturable(cuda_device, n_pos, precision):
     bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models], precision=precision)
     xs = [torch.from_numpy(x_np).cuda(), torch.from_numpy(np.ascontiguousarray(x_np[::-1])).cuda()]
     x = xs[0].clone()
+    assert bank.path_for(x) == {1: "single", 2: "single", 9: "tiled", 40: "stream"}[n_pos]
     bits = torch.empty((n_pos, 2100), dtype=torch.uint8, device="cuda")
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):

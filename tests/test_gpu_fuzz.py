@@ -190,11 +190,11 @@ def test_wide_decoder_random_shapes(cuda_device, seed):
 
 
 @pytest.mark.parametrize("seed", range(12 * SCALE))
-def test_fused_chain_random_shapes(cuda_device, seed, monkeypatch):
+def test_fused_chain_random_shapes(cuda_device, seed):
     """K6 (one persistent launch for the whole chain): random eligible shapes -- 1..7 hidden layers of width 1..512, an even
     row length <= 512, 2..32 classes (vector-ALU head) or 33..512 (MFMA class layer + LDS argmax), tanh or ReLU, matrix
     rows or windows of a stream -- against float64 AND against the
-    layer-at-a-time path (NNV_WIDE_FUSED=0), whose hidden layers are bit-identical by construction."""
+    layer-at-a-time path (set_path), whose hidden layers are bit-identical by construction."""
     rng = np.random.RandomState(5000 + seed)
     n_hidden = int(rng.randint(1, 8))
     top = int(rng.choice([40, 130, 512]))
@@ -212,11 +212,11 @@ def test_fused_chain_random_shapes(cuda_device, seed, monkeypatch):
         x = rng.randn(n, dims[0]).astype(np.float32)
         xd = torch.from_numpy(x).cuda()
         run = lambda: net.decode(xd, want_act=True)
-    monkeypatch.delenv("NNV_WIDE_FUSED", raising=False)
+    assert net.path == "fused"
     fused = run()
-    monkeypatch.setenv("NNV_WIDE_FUSED", "0")
+    net.set_path("layered")
+    assert net.path == "layered"
     layered = run()
-    monkeypatch.delenv("NNV_WIDE_FUSED", raising=False)
     act = fused["act"].cpu().numpy()
     _check_ff(fused["cls32"].cpu().numpy(), act, x, Ws, bs, activation)
     scale = 1.0 if activation == "tanh" else max(1.0, float(np.abs(act).max()))

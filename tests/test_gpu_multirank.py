@@ -6,9 +6,12 @@
   all_reduce_counters runs here and nowhere else).
 * `test_bench_two_ranks_one_gpu_rehearsal`: the same 2-rank code path with the counters reduced over
   gloo, both ranks on GPU 0 (NNV_DIST_BACKEND=gloo) - runs on the 1-GPU box.
-Both check `ranks_seen`, the per-rank device indices, and that the error counters of the 2-rank
+* `test_bench_four_ranks_one_gpu_rehearsal`: 4 ranks over gloo on GPU 0 (uneven shard of the configs[3] leg).
+All check `ranks_seen`, the per-rank device indices, and that the error counters of the N-rank
 run equal those of ONE rank decoding the same global blocks (the generator is keyed by the global
-row, so the data cannot depend on the rank count)."""
+row, so the data cannot depend on the rank count) -- for the headline workload AND for the
+BASELINE configs[3] leg (block_len 1024, mixed SNR, per-SNR-bin counters through the one all-reduce):
+the [7, 4] counters of the N-rank run are the single-rank run's integers, bit for bit."""
 import json
 import os
 import subprocess
@@ -19,15 +22,18 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BLOCKS = 60_000            # per GPU; 480 k rows
+CONFIG3_BLOCKS = 7 * 301 + 5   # configs[3] leg: 2,112 blocks of 128 rows, not divisible by 2, 4 or 7 (ragged shards and bins)
 
 
 def _bench(n_gpus, blocks_per_gpu, extra_env=None):
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NNV_BENCH_SMALL_LEGS"] = "1"           # the one-rank run's other legs at reduced size (not what is tested here)
+    env["NNV_BENCH_LIVE_TRAFFIC"] = "0"
     env.update(extra_env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_gpus),
                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                        "--blocks-per-gpu", str(blocks_per_gpu)],
+                        "--blocks-per-gpu", str(blocks_per_gpu), "--config3-blocks", str(CONFIG3_BLOCKS)],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -35,13 +41,35 @@ def _bench(n_gpus, blocks_per_gpu, extra_env=None):
     return json.loads(lines[0])
 
 
-def _check_pair(two, one):
-    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2
+def _check_config3(multi, one, world):
+    """BASELINE configs[3] through `bench.py --gpus N`: the same total work for every N (strong scaling), contiguous
+    block shards, per-SNR-bin counters reduced by the one all-reduce == the single-rank run's integers."""
+    m, o = multi["other_baseline_configs"]["configs[3]"], one["other_baseline_configs"]["configs[3]"]
+    assert "error" not in m and "error" not in o, (m, o)
+    assert m["n_gpus"] == world and o["n_gpus"] == 1 and m["scaling"] == "strong"
+    assert m["blocks_total"] == o["blocks_total"] == CONFIG3_BLOCKS
+    assert sum(m["blocks_per_rank"]) == CONFIG3_BLOCKS and len(m["blocks_per_rank"]) == world
+    assert max(m["blocks_per_rank"]) - min(m["blocks_per_rank"]) <= 1
+    assert len(m["seconds_per_rank"]) == world and m["value"] > 0
+    assert m["counters"] == o["counters"]                       # [7][4] int64, bit for bit
+    assert m["ber_by_snr_db"] == o["ber_by_snr_db"] and m["fer_by_snr_db"] == o["fer_by_snr_db"]
+    c = o["counters"]
+    assert sum(row[3] for row in c) == CONFIG3_BLOCKS * 128 and all(row[2] == 8 * row[3] for row in c)
+    assert [row[3] for row in c] == [128 * len(range(d, CONFIG3_BLOCKS, 7)) for d in range(7)]   # block i -> bin i % 7
+    ber = [o["ber_by_snr_db"][str(d)] for d in range(7)]
+    assert all(ber[d] > ber[d + 1] for d in range(6))           # the trained network: BER falls with the SNR
+    # rank 0's own share is a strict part of the whole
+    assert sum(r[3] for r in m["counters_rank0_before_all_reduce"]) == m["blocks_per_rank"][0] * 128
+
+
+def _check_pair(two, one, world=2):
+    assert two["n_gpus"] == world and two["ranks_seen"] == world
     assert two["scaling"] == "weak" and two["config"]["blocks_per_gpu"] == BLOCKS
     # 2 ranks x K steps over blocks [0, 2B) == 1 rank x K steps over the same blocks
     assert two["ber"] == one["ber"] and two["fer"] == one["fer"]
     assert two["block_error_rate"] == one["block_error_rate"]
     assert two["value"] > 0 and two["roofline"]["frac"] > 0
+    _check_config3(two, one, world)
 
 
 @pytest.mark.gpu
@@ -52,6 +80,15 @@ def test_bench_two_ranks_one_gpu_rehearsal(cuda_device):
     assert two["dist_backend"] == "gloo" and two["rank_devices"] == [0, 0]
     assert one["ranks_seen"] == 1 and one["rank_devices"] == [0]
     _check_pair(two, one)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_bench_four_ranks_one_gpu_rehearsal(cuda_device):
+    four = _bench(4, BLOCKS, {"NNV_DIST_BACKEND": "gloo"})
+    one = _bench(1, 4 * BLOCKS)
+    assert four["dist_backend"] == "gloo" and four["rank_devices"] == [0, 0, 0, 0]
+    _check_pair(four, one, world=4)
 
 
 @pytest.mark.gpu

@@ -241,14 +241,16 @@ def test_default_precision_switch_reaches_the_reference_shaped_modules(cuda_devi
 
 
 # ------------------------------------------------------------------ K6: the whole chain in one launch
-def _both_paths(monkeypatch, fn):
-    """fn() through the fused launch (default) and through the layer-at-a-time path (NNV_WIDE_FUSED=0,
-    read per call)."""
-    monkeypatch.delenv("NNV_WIDE_FUSED", raising=False)
+def _both_paths(net, fn, expect_fused=True):
+    """fn() through the handle's default kernel and through the layer-at-a-time path (WideMLP.set_path, C ABI
+    nnv_wide_set_path); the handle says which kernel each call ran."""
+    net.set_path("auto")
+    assert net.path == ("fused" if expect_fused else "layered")
     fused = fn()
-    monkeypatch.setenv("NNV_WIDE_FUSED", "0")
+    net.set_path("layered")
+    assert net.path == "layered"
     layered = fn()
-    monkeypatch.delenv("NNV_WIDE_FUSED", raising=False)
+    net.set_path("auto")
     return fused, layered
 
 
@@ -272,7 +274,7 @@ FUSED_SHAPES = [
 
 @pytest.mark.parametrize("dims,activation", FUSED_SHAPES)
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 4099])
-def test_fused_chain_matches_the_oracle_and_the_layered_path(cuda_device, monkeypatch, dims, activation, n):
+def test_fused_chain_matches_the_oracle_and_the_layered_path(cuda_device, dims, activation, n):
     """K6 (nnv_wide_fused.hip): the hidden activations never leave the CU.  Same contract as the layer-at-a-time
     path -- outputs within 1e-5 of float64, classes differ only on float64 near-ties -- and the two HIP paths agree
     with each other to the last bits of the class layer's different summation order (checked: 2e-6)."""
@@ -280,7 +282,7 @@ def test_fused_chain_matches_the_oracle_and_the_layered_path(cuda_device, monkey
     net = WideMLP(Ws, bs, activation=activation)
     x = (np.random.RandomState(n).randn(n, dims[0]) * 0.9).astype(np.float32)
     xd = torch.from_numpy(x).cuda()
-    fused, layered = _both_paths(monkeypatch, lambda: net.decode(xd, want_act=True, want_cls64=True))
+    fused, layered = _both_paths(net, lambda: net.decode(xd, want_act=True, want_cls64=True))
     act = fused["act"].cpu().numpy()
     cls = fused["cls32"].cpu().numpy()
     c64, _, o64 = O.decode(x, Ws, bs, 1, np.float64, activation=activation)
@@ -296,7 +298,7 @@ def test_fused_chain_matches_the_oracle_and_the_layered_path(cuda_device, monkey
     net.close()
 
 
-def test_fused_chain_on_a_stream_with_every_alignment(cuda_device, monkeypatch):
+def test_fused_chain_on_a_stream_with_every_alignment(cuda_device):
     """Windows of a stream (stride 2: 8-byte aligned rows), the same rows as a matrix (16-byte aligned when the row
     length allows), a stream that does not start on a 16-byte boundary, and a tail block of 1 row."""
     dims = [200, 500, 500, 500, 500, 2]
@@ -308,7 +310,7 @@ def test_fused_chain_on_a_stream_with_every_alignment(cuda_device, monkeypatch):
     x = np.ascontiguousarray(np.lib.stride_tricks.sliding_window_view(s, 200)[::2])
     for first in (0, 1):                                    # window `first` starts 8 * first bytes into the allocation
         view = sd[2 * first:]
-        fused, layered = _both_paths(monkeypatch, lambda: net.decode_stream(view, n, want_act=True))
+        fused, layered = _both_paths(net, lambda: net.decode_stream(view, n, want_act=True))
         rows = x[first:first + n]
         _check(fused["cls32"].cpu().numpy(), fused["act"].cpu().numpy(), rows, Ws, bs)
         assert np.abs(fused["act"].cpu().numpy() - layered["act"].cpu().numpy()).max() < 2e-6
@@ -342,17 +344,20 @@ def test_fused_chain_is_deterministic_and_row_independent(cuda_device):
     net.close()
 
 
-def test_shapes_outside_the_fused_kernel_take_the_layered_path(cuda_device, monkeypatch):
+def test_shapes_outside_the_fused_kernel_take_the_layered_path(cuda_device):
     """Hidden width above 512, row length above 512, a class layer wider than 512 and the f16x3 mode are not eligible:
-    the layer-at-a-time path decodes them, with or without the switch."""
+    the layer-at-a-time path decodes them whatever the handle is pinned to, and pinning them to K6 is refused."""
     for dims, kw in (([100, 600, 2], {}), ([1036, 30, 2], {"activation": "relu"}), ([16, 256, 128, 64, 1024], {}),
                      ([200, 500, 500, 2], {"precision": "f16x3"})):
         Ws, bs = _net(dims, 2)
         net = WideMLP(Ws, bs, **kw)
         x = np.random.RandomState(3).randn(300, dims[0]).astype(np.float32)
         xd = torch.from_numpy(x).cuda()
-        a, b = _both_paths(monkeypatch, lambda: net.decode(xd, want_act=True))
+        a, b = _both_paths(net, lambda: net.decode(xd, want_act=True), expect_fused=False)
         assert torch.equal(a["act"], b["act"]) and torch.equal(a["cls32"], b["cls32"])
+        with pytest.raises(Exception, match="unsupported"):
+            net.set_path("fused")
+        assert net.path == "layered"
         c64, _, o64 = O.decode(x, Ws, bs, 1, np.float64, activation=kw.get("activation", "tanh"))
         assert np.abs(a["act"].cpu().numpy() - o64).max() < 2e-5 * max(1.0, np.abs(o64).max())
         net.close()

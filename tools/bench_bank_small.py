@@ -41,11 +41,10 @@ for P in args.positions:
         wp, bp = bw.initialize_weights(cfg, rng=np.random.RandomState(100 + p))
         models.append((wp["h1"], bp["b1"], wp["out"], np.array([0.01, 0.0], np.float32)))
     bank = BitwiseBank(models, precision=args.precision)
-    os.environ.pop("NNV_BANK_SINGLE", None)
     ms_d, r_d = timed(lambda: bank.decode(x), args.steps)
-    os.environ["NNV_BANK_SINGLE"] = "0"
+    bank.set_path("tiled")
     ms_t, r_t = timed(lambda: bank.decode(x), args.steps)
-    del os.environ["NNV_BANK_SINGLE"]
+    bank.set_path("auto")
     differ = int((r_d["bits"] != r_t["bits"]).sum().item())
     out["legs"].append({"positions": P, "default_ms": ms_d, "tiled_K4b_ms": ms_t,
                         "default_hbm_frac_per_position_pass": 4 * cfg.n_input * n * P / (ms_d * 1e-3) / 8e12,

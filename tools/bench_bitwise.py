@@ -62,11 +62,9 @@ for p in range(P):
     models.append((wp["h1"], bp["b1"], wp["out"], np.array([0.01, 0.0], np.float32)))
 bank = BitwiseBank(models)
 msP, rP = timed(lambda: bank.decode(x), max(2, args.steps // 4))        # K4c: rows resident in LDS, first layers streamed
-os.environ["NNV_BANK_STREAM"] = "0"                                      # K4b: the LDS-tiled GEMM (read per call)
-os.environ["NNV_BANK_SINGLE"] = "0"
+bank.set_path("tiled")                                                   # K4b: the LDS-tiled GEMM
 msPt, rPt = timed(lambda: bank.decode(x), max(2, args.steps // 4))
-del os.environ["NNV_BANK_STREAM"]
-del os.environ["NNV_BANK_SINGLE"]
+bank.set_path("auto")
 tiled_same = bool(torch.equal(rPt["bits"], rP["bits"]))
 bitsP = rP["bits"][:, :m].cpu().numpy()
 mismP = 0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Secondary benchmark (NOT the headline; bench.py is): the reference's sliding-window decoder
 forward (src/fnn_viterbi_seq_predict.py: 200 -> 500 x4 -> 2, window i = stream[2i : 2i+200]): the whole chain
-in one persistent launch (K6, the default), the layer-at-a-time path beside it (K4, NNV_WIDE_FUSED=0) and its f16x3
+in one persistent launch (K6, the default), the layer-at-a-time path beside it (K4, WideMLP.set_path) and its f16x3
 mode, with the oracle's C restatement timed on a bounded sample.
 Prints one JSON line.  Usage: python tools/bench_seq_predict.py [--windows 1000000] [--steps 10]"""
 import argparse, json, os, sys, time
@@ -33,7 +33,7 @@ for _ in range(args.steps):
     r = net.decode_stream(stream, n)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / args.steps
-os.environ["NNV_WIDE_FUSED"] = "0"          # read per call by nnv_wide_decode_f32: the layer-at-a-time path
+net.set_path("layered")                    # nnv_wide_set_path: the layer-at-a-time path
 for _ in range(2):
     rl = net.decode_stream(stream, n)
 torch.cuda.synchronize()
@@ -43,7 +43,7 @@ for _ in range(args.steps):
 e1.record(); torch.cuda.synchronize()
 ms_layered = e0.elapsed_time(e1) / args.steps
 layered_diff = int((rl["cls32"] != r["cls32"]).sum().item())
-del os.environ["NNV_WIDE_FUSED"]
+net.set_path("auto")
 fast = WideMLP(Ws, bs, precision="f16x3")
 for _ in range(2):
     rf = fast.decode_stream(stream, n)

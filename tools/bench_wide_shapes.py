@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Feed-forward decoders whose hidden widths the register-chained kernel (K1) has no instantiation for
 (`DecoderConfig(n_hidden_1=..., ...)` are free parameters of the reference, src/fnn_viterbi.py:35-37): the whole
-chain in one persistent launch (K6) against the layer-at-a-time path (K4, NNV_WIDE_FUSED=0, read per call).
+chain in one persistent launch (K6) against the layer-at-a-time path (K4, WideMLP.set_path).
 One JSON line per shape.  Usage: python tools/bench_wide_shapes.py [rows]"""
 import json, os, sys
 import numpy as np, torch
@@ -21,11 +21,8 @@ for dims in ([14, 100, 100, 100, 128], [14, 200, 96, 48, 128], [16, 256, 128, 64
     flop = 2 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
     out = {"net": dims, "rows": rows, "flop_per_row": flop}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for name, env in (("fused_K6", None), ("layered_K4", "0")):
-        if env is None:
-            os.environ.pop("NNV_WIDE_FUSED", None)
-        else:
-            os.environ["NNV_WIDE_FUSED"] = env
+    for name, path in (("fused_K6", "auto"), ("layered_K4", "layered")):
+        net.set_path(path)
         r = net.decode(x)
         torch.cuda.synchronize()
         e0.record()
@@ -36,6 +33,5 @@ for dims in ([14, 100, 100, 100, 128], [14, 200, 96, 48, 128], [16, 256, 128, 64
         ms = e0.elapsed_time(e1) / 5
         out[name] = {"ms": ms, "rows_per_s": rows / (ms * 1e-3), "frac_of_fp32_mfma_peak": flop * rows / (ms * 1e-3) / 1e12 / 157.3,
                      "cls_checksum": int(r["cls32"].to(torch.int64).sum().item())}
-    os.environ.pop("NNV_WIDE_FUSED", None)
     net.close()
     print(json.dumps(out))

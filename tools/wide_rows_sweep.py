@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """K6 (whole chain in one persistent launch) against K4 (one launch per layer) over the NUMBER OF ROWS: the
-sliding-window decoder's network 200 -> 500 x 4 -> 2 and two narrower ones.  NNV_WIDE_FUSED is read per call.
+sliding-window decoder's network 200 -> 500 x 4 -> 2 and two narrower ones.  The handle is pinned with WideMLP.set_path.
 Usage: python tools/wide_rows_sweep.py"""
 import json, os, sys
 import numpy as np, torch
@@ -30,11 +30,11 @@ for dims in ([200, 500, 500, 500, 500, 2], [16, 256, 128, 64, 256], [20, 300, 30
     for n in (64, 512, 2048, 8192, 16384, 32768, 65536, 262144, 1048576):
         x = torch.randn((n, dims[0]), device="cuda")
         steps = 200 if n <= 65536 else 20
-        os.environ.pop("NNV_WIDE_FUSED", None)
+        net.set_path("auto")
         a = timed(lambda: net.decode(x), steps)
-        os.environ["NNV_WIDE_FUSED"] = "0"
+        net.set_path("layered")
         b = timed(lambda: net.decode(x), steps)
-        del os.environ["NNV_WIDE_FUSED"]
+        net.set_path("auto")
         out.append({"dims": dims, "rows": n, "K6_us": a * 1e3, "K4_us": b * 1e3})
         print("%-28s rows %8d  K6 %9.1f us  K4 %9.1f us  K4/K6 %.2f" % ("-".join(map(str, dims)), n, a * 1e3, b * 1e3, b / a), flush=True)
     net.close()
