@@ -245,6 +245,8 @@ int32_t nnv_awgn_generate_f32(int32_t code, int32_t tile_bits, int64_t n_rows,
  *    whenever the shape allows it.)
  * ------------------------------------------------------------------------ */
 #define NNV_WIDE_MAX_LAYERS 8
+#define NNV_WIDE_MAX_WIDTH 16384   /* row length and hidden widths; wider: NNV_ERR_UNSUPPORTED_SHAPE */
+#define NNV_WIDE_MAX_CLASSES 65536 /* class layer (block_length <= 16 as 2^b classes); wider: NNV_ERR_UNSUPPORTED_SHAPE */
 
 typedef enum nnv_activation {
   NNV_ACT_TANH = 0, /* src/fnn_viterbi_seq_predict.py:408-412 */

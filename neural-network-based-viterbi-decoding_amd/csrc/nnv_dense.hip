@@ -47,9 +47,15 @@ __device__ __forceinline__ float dense_tanh_f32(float z) {
 // P independent networks' hidden layers, 32 columns per bit position (30 used), and the epilogue
 // finishes each network in place -- relu(h . Wout + bout) -> argmax over its 2 outputs -- so that the
 // [rows, 32 P] hidden matrix never goes to HBM; one decided bit per (position, row) leaves instead.
-template <bool GATHER, int kBK, int ACT, int BN, bool HEAD = false>
+// CLS (a WIDE class layer, 33..65536 classes -- e.g. the reference's DecoderConfig at block_length 13..15, 32 -> 2^b):
+// the epilogue keeps, per row, the first maximum of the activated outputs over this block's 128 columns and writes one
+// (value, class) pair per (row, column block) instead of the tile: the [rows, 2^b] output matrix (128 KB per row at
+// b = 15) never goes to HBM; partial_argmax_kernel merges the pairs.  Same values, same first-maximum rule as
+// materialising the row and scanning it (row_argmax_kernel, which stays for the debug output).
+template <bool GATHER, int kBK, int ACT, int BN, bool HEAD = false, bool CLS = false>
 __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
   static_assert(BN == 128 || (BN == 32 && kBK == 32), "tile shapes");
+  static_assert(!(HEAD && CLS) && (!CLS || BN == 128), "one epilogue at a time; the class epilogue has the 128-column tile only");
   constexpr int kBN = BN;                   // shadows the namespace constant inside this kernel
   constexpr int WT = BN == 128 ? 2 : 1;     // 32 x 32 MFMA tiles per wave, per dimension
   constexpr int kLdsStride = kBK + 4;
@@ -272,6 +278,38 @@ __global__ __launch_bounds__(256) void dense_tanh_kernel(const DenseParams p) {
       }
       continue;
     }
+    if constexpr (CLS) {
+      // 64 staged rows x 128 activated columns: 4 threads per row, 32 columns each, merged by two xor-shuffles
+      const int lrow = tid >> 2, seg = tid & 3;
+      const float *hv = stage + lrow * kOutStride + 32 * seg;
+      float best = -__builtin_inff();
+      int bidx = 0x7fffffff;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4 *>(hv + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = col0 + 32 * seg + 4 * q + e;
+          const bool take = c < p.n_valid && v4[e] > best;   // strict >: the lowest index keeps a tie
+          best = take ? v4[e] : best;
+          bidx = take ? c : bidx;
+        }
+      }
+#pragma unroll
+      for (int off = 1; off <= 2; off <<= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bidx, off);
+        const bool take = ov > best || (ov == best && oi < bidx);
+        best = take ? ov : best;
+        bidx = take ? oi : bidx;
+      }
+      const int64_t row = row0 + (lrow >> 5) * 32 * WT + 32 * a + (lrow & 31);
+      if (seg == 0 && row < p.n_rows) {
+        p.part_val[row * p.nblk_m + col_blk] = best;
+        p.part_idx[row * p.nblk_m + col_blk] = bidx;
+      }
+      continue;
+    }
 #pragma unroll
     for (int it = 0; it < (kStageRows * kChunksPerRow) / 256; ++it) {
       const int chunk = tid + 256 * it;
@@ -321,7 +359,48 @@ __global__ __launch_bounds__(256) void head_argmax_kernel(const HeadParams p) {
   }
 }
 
-nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream) {
+// one 32-lane group per row: first maximum over its nblk (value, class) pairs
+__global__ __launch_bounds__(256) void partial_argmax_kernel(const float *pv, const int32_t *pi, int64_t n_rows, int nblk,
+                                                             int32_t *cls32, int64_t *cls64) {
+  const int lane = threadIdx.x & 31;
+  const int64_t row = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 5;
+  if (row >= n_rows) return;
+  float best = -__builtin_inff();
+  int bidx = 0x7fffffff;
+  for (int c = lane; c < nblk; c += 32) {
+    const float v = pv[row * nblk + c];
+    const int i = pi[row * nblk + c];
+    if (v > best || (v == best && i < bidx)) {
+      best = v;
+      bidx = i;
+    }
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 32);
+    const int oi = __shfl_xor(bidx, off, 32);
+    if (ov > best || (ov == best && oi < bidx)) {
+      best = ov;
+      bidx = oi;
+    }
+  }
+  if (lane == 0) {
+    if (bidx == 0x7fffffff) bidx = 0;   // a row of NaNs: unspecified, but a class
+    if (cls32) cls32[row] = bidx;
+    if (cls64) cls64[row] = bidx;
+  }
+}
+
+nnv_status partial_argmax_launch(const float *part_val, const int32_t *part_idx, int64_t n_rows, int32_t nblk,
+                                 int32_t *cls32, int64_t *cls64, hipStream_t stream) {
+  const int64_t blocks = (n_rows * 32 + 255) / 256;
+  if (blocks <= 0 || blocks > 0x7fffffffLL || nblk < 1) return NNV_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(partial_argmax_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, part_val, part_idx,
+                     n_rows, nblk, cls32, cls64);
+  return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+}
+
+nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream, bool cls) {
   const int64_t blocks = (p.nblk_rows + 7) / 8 * 8 * p.nblk_m;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return NNV_ERR_INVALID_ARGUMENT;
   // BK = 64 measured 6 % slower than BK = 32 on the 512x512 layers (more staging registers and LDS,
@@ -331,6 +410,12 @@ nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream) {
   if (p.act != 1 && p.act != 2) return NNV_ERR_INVALID_ARGUMENT;
   if (p.bn != 128 && p.bn != 32) return NNV_ERR_INVALID_ARGUMENT;
   const bool tanh_act = p.act == 1;
+  if (cls) {  // a wide class layer with the argmax in the epilogue (never the first layer: depth >= 2)
+    if (gather || p.bn != 128 || !p.part_val || !p.part_idx || p.n_valid < 1) return NNV_ERR_INVALID_ARGUMENT;
+    if (tanh_act) hipLaunchKernelGGL((dense_tanh_kernel<false, 32, 1, 128, false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((dense_tanh_kernel<false, 32, 2, 128, false, true>), grid, block, 0, stream, p);
+    return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+  }
 #define NNV_DENSE_LAUNCH(G, BK, BNV)                                                              \
   do {                                                                                            \
     if (tanh_act) hipLaunchKernelGGL((dense_tanh_kernel<G, BK, 1, BNV>), grid, block, 0, stream, p); \

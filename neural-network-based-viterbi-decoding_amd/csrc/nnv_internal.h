@@ -217,6 +217,11 @@ struct DenseParams {
   float *head_act;             // nullable [n_pos][n_rows][2] ReLU'd outputs (parity)
   const uint8_t *labels;       // nullable [n_pos][n_rows] true bit
   unsigned long long *errors;  // nullable [n_pos] wrong decisions, ACCUMULATED (needs labels)
+  // fused class-layer argmax (dense_launch with cls = true): per (row, column block) the first maximum of the
+  // activated outputs over the block's valid columns; C is not written
+  int32_t n_valid;             // true class count (columns >= n_valid are padding and never win)
+  float *part_val;             // [n_rows][nblk_m]
+  int32_t *part_idx;           // [n_rows][nblk_m] global class index of that maximum
 };
 struct HeadParams {
   const float *A;        // [n_rows][lda]
@@ -273,7 +278,10 @@ struct HeadF16Params {
 };
 nnv_status dense_f16x3_launch(const DenseF16Params &p, bool gather, hipStream_t stream);
 nnv_status head_f16x3_launch(const HeadF16Params &p, hipStream_t stream);
-nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream);
+nnv_status dense_launch(const DenseParams &p, bool gather, hipStream_t stream, bool cls = false);
+// first maximum over the nblk partial (value, class) pairs of every row (ties: the lower class index)
+nnv_status partial_argmax_launch(const float *part_val, const int32_t *part_idx, int64_t n_rows, int32_t nblk,
+                                 int32_t *cls32, int64_t *cls64, hipStream_t stream);
 nnv_status bitwise_launch(const DenseParams &p, hipStream_t stream);
 nnv_status bitwise_f16x3_launch(const DenseF16Params &p, hipStream_t stream);
 nnv_status head_launch(const HeadParams &p, hipStream_t stream);

@@ -174,7 +174,12 @@ int32_t nnv_wide_prepack(const nnv_wide_desc *net, nnv_wide_handle **out) {
   if (net->depth < 2 || net->depth > NNV_WIDE_MAX_LAYERS) return NNV_ERR_UNSUPPORTED_SHAPE;
   if (net->activation != NNV_ACT_TANH && net->activation != NNV_ACT_RELU) return NNV_ERR_INVALID_ARGUMENT;
   for (int l = 0; l <= net->depth; ++l)
-    if (net->dims[l] < 1 || net->dims[l] > 16384) return NNV_ERR_INVALID_ARGUMENT;
+    if (net->dims[l] < 1) return NNV_ERR_INVALID_ARGUMENT;
+  // widths: NNV_WIDE_MAX_WIDTH per layer, NNV_WIDE_MAX_CLASSES for the class layer (2^16: the reference's
+  // DecoderConfig goes to block_length 15 = 32768 classes in its own tests, tests/test_utilities.py:342-348)
+  for (int l = 0; l < net->depth; ++l)
+    if (net->dims[l] > NNV_WIDE_MAX_WIDTH) return NNV_ERR_UNSUPPORTED_SHAPE;
+  if (net->dims[net->depth] > NNV_WIDE_MAX_CLASSES) return NNV_ERR_UNSUPPORTED_SHAPE;
   for (int l = 0; l < net->depth; ++l)
     if (!net->W_host[l] || !net->b_host[l]) return NNV_ERR_INVALID_ARGUMENT;
   int dev = 0;
@@ -402,12 +407,27 @@ int32_t nnv_wide_decode_f32(const nnv_wide_handle *h, const float *x_dev, int64_
       dp.nblk_m = h->mpad[l] / h->bn[l];
       dp.nblk_rows = (rows + nnv::kDenseBM - 1) / nnv::kDenseBM;
       dp.act = h->act;
+      if (l == last && !act_dev && h->bn[l] == 128 && l > 0) {
+        // wide class layer: argmax in the GEMM epilogue, one (value, class) pair per (row, 128-column block) instead
+        // of the [rows, n_classes] matrix (the pairs reuse the buffer the matrix would have taken: 8 bytes per block
+        // against its 512)
+        dp.C = nullptr;
+        dp.n_valid = h->dims[h->depth];
+        dp.part_val = buf[cur];
+        dp.part_idx = reinterpret_cast<int32_t *>(buf[cur] + chunk * dp.nblk_m);
+        nnv_status st = nnv::dense_launch(dp, false, s, true);
+        if (st != NNV_OK) return st;
+        st = nnv::partial_argmax_launch(dp.part_val, dp.part_idx, rows, dp.nblk_m, cls32_dev ? cls32_dev + done : nullptr,
+                                        cls64_dev ? cls64_dev + done : nullptr, s);
+        if (st != NNV_OK) return st;
+        break;
+      }
       const nnv_status st = nnv::dense_launch(dp, l == 0, s);
       if (st != NNV_OK) return st;
       in = buf[cur];
       in_stride = h->mpad[l];
       cur ^= 1;
-      if (l == last) {  // wide class layer: argmax over the tanh'd row
+      if (l == last) {  // wide class layer with the debug output wanted (or a 33..64-class layer on the 32-column tile): argmax over the stored row
         const int64_t blocks = (rows * 32 + 255) / 256;
         hipLaunchKernelGGL(row_argmax_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, in,
                            in_stride, rows, h->dims[h->depth], cls32_dev ? cls32_dev + done : nullptr,

@@ -12,9 +12,10 @@ from __future__ import annotations
 
 import collections
 import ctypes
+import hashlib
+import itertools
 import os
-import weakref
-from typing import Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -80,6 +81,10 @@ def _stream_ptr(device) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+# Networks packed (prepack + upload) by this process, per kind: the tests of the caches below count them.
+PACK_STATS = {"mlp": 0, "wide": 0, "bank": 0, "seq2seq": 0}
+
+
 class PackedMLP:
     """A network pre-packed into MFMA fragment order, resident in HBM.
 
@@ -127,6 +132,7 @@ class PackedMLP:
                                                      _cabi.NNV_PRECISION[precision],
                                                      ctypes.byref(handle)), "nnv_mlp_prepack_ex")
         self._handle = handle
+        PACK_STATS["mlp"] += 1
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
@@ -328,7 +334,12 @@ class WideMLP:
             _cabi.check(self._lib.nnv_wide_prepack(ctypes.byref(desc), ctypes.byref(handle)),
                         "nnv_wide_prepack")
         self._handle = handle
-        nbytes = int(self._lib.nnv_wide_workspace_bytes(handle, int(chunk_rows)))
+        PACK_STATS["wide"] += 1
+        # two activation buffers of chunk_rows x the widest padded layer; a very wide CLASS layer (2^13..2^16 classes)
+        # would make that tens of GB, so the chunk shrinks until the workspace is at most 2 GiB (>= 128 rows)
+        per_128 = int(self._lib.nnv_wide_workspace_bytes(handle, 128))
+        rows = max(128, min(int(chunk_rows), (2 << 30) // per_128 * 128))
+        nbytes = int(self._lib.nnv_wide_workspace_bytes(handle, rows))
         self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
     def close(self):
@@ -427,6 +438,7 @@ class BitwiseBank:
             _cabi.check(self._lib.nnv_bitwise_prepack_ex(ctypes.byref(desc), _cabi.NNV_PRECISION[self.precision],
                                                          ctypes.byref(handle)), "nnv_bitwise_prepack_ex")
         self._handle = handle
+        PACK_STATS["bank"] += 1
 
     def close(self):
         h, self._handle = getattr(self, "_handle", None), None
@@ -520,6 +532,7 @@ class Seq2SeqLSTM:
             _cabi.check(self._lib.nnv_seq2seq_prepack(ctypes.byref(desc), ctypes.byref(handle)),
                         "nnv_seq2seq_prepack")
         self._handle = handle
+        PACK_STATS["seq2seq"] += 1
 
     def close(self):
         h, self._handle = getattr(self, "_handle", None), None
@@ -597,6 +610,45 @@ def generate_awgn_blocks(code: str, tile_bits: int, n_rows: int, sigma, seed: in
 
 
 # ---------------------------------------------------------------------------
+# Packed networks of the REFERENCE-SHAPED calls.  ``fnn_viterbi.predict(test_set, weights, biases)``,
+# ``run_graph(model)``, ``fnn_viterbi_seq_predict.predict_stream`` ... take the weights as host dictionaries on every
+# call, like the reference's Session.run takes them from its variables.  Packing + upload + a synchronising free
+# around a 0.4 ms decode would dominate an SNR loop, so those modules keep the packed network here, keyed by the
+# BYTES of the weights (a digest: robust against in-place edits, new array objects over the same values, reloads),
+# the precision and the device -- one prepack for the life of the call site's weights, least-recently-used eviction.
+# ---------------------------------------------------------------------------
+_NET_CACHE: "collections.OrderedDict[tuple, object]" = collections.OrderedDict()
+_NET_CACHE_MAX = 8
+
+
+def _content_digest(arrays: Sequence) -> bytes:
+    h = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        a = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+        h.update(repr(a.shape).encode())
+        h.update(a.view(np.uint8).reshape(-1).data)
+    return h.digest()
+
+
+def cached_network(kind: str, arrays: Sequence, build: Callable[[], object], extra: tuple = ()):
+    """The packed network of ``kind`` for the host ``arrays`` (weights and biases, in a fixed order): built by
+    ``build()`` on first use, then shared by every later call with the same bytes, ``extra`` (precision, activation ...)
+    and current device.  The caller must NOT close it; ``clear_pack_cache()`` releases everything."""
+    _require_cuda()
+    key = (kind, torch.cuda.current_device(), _DEFAULT_PRECISION[0], tuple(extra), _content_digest(arrays))
+    net = _NET_CACHE.get(key)
+    if net is not None:
+        _NET_CACHE.move_to_end(key)
+        return net
+    while len(_NET_CACHE) >= _NET_CACHE_MAX:
+        _, old = _NET_CACHE.popitem(last=False)
+        old.close()
+    net = build()
+    _NET_CACHE[key] = net
+    return net
+
+
+# ---------------------------------------------------------------------------
 # torch custom ops:  torch.ops.nnviterbi.mlp_decode / mlp_forward
 #   one schema, two dispatch keys (SURVEY.md 8b "Operator"):
 #     CUDA (= HIP on ROCm): the fused gfx950 kernel through the C ABI
@@ -639,10 +691,14 @@ def _evict(key) -> None:
 
 
 def clear_pack_cache() -> None:
-    """Drop every network the torch ops have packed (frees their HBM; never needed for correctness:
-    an entry is only used while the weights' bytes equal the ones it was packed from)."""
+    """Drop every network the raw-weights torch ops and the reference-shaped calls have packed (frees their HBM;
+    never needed for correctness: an entry is only used while the weights' bytes equal the ones it was packed from).
+    Handles made by ``nnviterbi::mlp_prepack`` belong to their caller and are not touched."""
     for key in list(_PACK_CACHE):
         _evict(key)
+    while _NET_CACHE:
+        _, net = _NET_CACHE.popitem()
+        net.close()
 
 
 def _sweep_dead_entries() -> None:
@@ -660,6 +716,21 @@ def _content_snapshot(tensors: List[torch.Tensor]) -> torch.Tensor:
     return torch.cat(flat).view(torch.int32)
 
 
+def _pack_any(weights, biases, device, precision: str):
+    """PackedMLP when the register-chained kernel has an instantiation for the shape, else the wide path (K6 for layers
+    up to 512 wide, one launch per layer beyond): hidden widths are free parameters of the reference's DecoderConfig.
+    Both run on the GPU, same tolerances."""
+    wide_precision = precision if len(biases[-1]) <= 32 else "f32"
+    if len(weights) > _cabi.NNV_MAX_LAYERS:               # deeper than K1 chains layers: the wide path (up to 8)
+        return WideMLP(weights, biases, device=device, precision=wide_precision)
+    try:
+        return PackedMLP(weights, biases, device=device, precision=precision)
+    except NNViterbiError as e:
+        if "unsupported network shape" not in str(e):
+            raise
+        return WideMLP(weights, biases, device=device, precision=wide_precision)
+
+
 def _cached_pack(weights: List[torch.Tensor], biases: List[torch.Tensor], device):
     from torch.multiprocessing.reductions import StorageWeakRef
     tensors = list(weights) + list(biases)
@@ -673,8 +744,9 @@ def _cached_pack(weights: List[torch.Tensor], biases: List[torch.Tensor], device
         # check (3) waits for the device, which a capturing stream forbids -- and a graph would replay the weights of
         # capture time anyway: say so instead of failing inside torch.equal
         raise RuntimeError("nnviterbi torch ops take raw weight tensors and verify their bytes on every call (a device "
-                           "wait): they cannot be captured into a HIP graph. Hold a decoder.PackedMLP / WideMLP and "
-                           "capture its decode() instead (pure kernel launches).")
+                           "wait): they cannot be captured into a HIP graph. Pack once with "
+                           "torch.ops.nnviterbi.mlp_prepack and capture torch.ops.nnviterbi.mlp_decode_packed (pure "
+                           "kernel launches on the capturing stream), or hold a decoder.PackedMLP / WideMLP.")
     snapshot = _content_snapshot(tensors)
     e = _PACK_CACHE.get(key)
     if e is not None:
@@ -684,19 +756,7 @@ def _cached_pack(weights: List[torch.Tensor], biases: List[torch.Tensor], device
         _evict(key)                                   # same storages, written in place since
     while len(_PACK_CACHE) >= _PACK_CACHE_MAX:
         _evict(next(iter(_PACK_CACHE)))               # least recently used
-    wide_precision = precision if len(biases[-1]) <= 32 else "f32"
-    if len(weights) > _cabi.NNV_MAX_LAYERS:               # deeper than K1 chains layers: the wide path (up to 8)
-        net = WideMLP(weights, biases, device=device, precision=wide_precision)
-    else:
-        try:
-            net = PackedMLP(weights, biases, device=device, precision=precision)
-        except NNViterbiError as e:
-            # hidden widths the register-chained kernel has no instantiation for (they are free parameters of the
-            # reference's DecoderConfig): the same ops run through the wide path -- one persistent launch for the
-            # whole chain up to 512-wide layers (K6), one launch per layer beyond -- still on the GPU, same tolerances
-            if "unsupported network shape" not in str(e):
-                raise
-            net = WideMLP(weights, biases, device=device, precision=wide_precision)
+    net = _pack_any(weights, biases, device, precision)
     _PACK_CACHE[key] = _PackEntry(net, [StorageWeakRef(st) for st in storages], versions, snapshot)
     return net
 
@@ -716,13 +776,14 @@ def _decode_with(net, x: torch.Tensor, tile_bits: int, labels: Optional[torch.Te
     cls = net.decode(x, want_cls64=True)["cls64"]
     shifts = torch.arange(tile_bits - 1, -1, -1, dtype=torch.int64, device=x.device)
     bits = ((cls[:, None] >> shifts[None, :]) & 1).to(torch.uint8)
-    counters = torch.zeros(4, dtype=torch.int64, device=x.device)
-    if labels is not None:
-        diff = cls ^ labels.to(torch.int64)
-        counters[0] = ((diff[:, None] >> shifts[None, :]) & 1).sum()
-        counters[1] = (diff != 0).sum()
-        counters[2] = x.shape[0] * tile_bits
-        counters[3] = x.shape[0]
+    if labels is None:
+        return cls, bits, torch.zeros(4, dtype=torch.int64, device=x.device)
+    # device arithmetic only (fill kernels, no host-to-device copies): the op must stay capturable into a HIP graph
+    diff = cls ^ labels.to(torch.int64)
+    n = x.shape[0]
+    counters = torch.stack([((diff[:, None] >> shifts[None, :]) & 1).sum(), (diff != 0).sum(),
+                            torch.full((), n * tile_bits, dtype=torch.int64, device=x.device),
+                            torch.full((), n, dtype=torch.int64, device=x.device)])
     return cls, bits, counters
 
 
@@ -808,3 +869,99 @@ def _mlp_forward_cpu(x, weights, biases):
 @mlp_forward.register_fake
 def _(x, weights, biases):
     return x.new_empty((x.shape[0], biases[-1].shape[0]), dtype=torch.float32)
+
+
+# ---------------------------------------------------------------------------
+# Handle-based ops (SURVEY.md 8b "Threading": stream-ordered, re-entrant, no global state besides the handle table):
+#   h = torch.ops.nnviterbi.mlp_prepack(weights, biases, "f32")        once: pack + upload (synchronous)
+#   cls, bits, counters = torch.ops.nnviterbi.mlp_decode_packed(x, h, tile_bits, labels)
+#   out = torch.ops.nnviterbi.mlp_forward_packed(x, h)
+#   torch.ops.nnviterbi.mlp_free(h)
+# A decode is kernel launches on the CURRENT stream and allocations from torch's caching allocator: no host wait, no
+# lookup by content, nothing evicted behind the caller's back -- so it can be captured into a HIP graph and replayed on
+# new inputs (tests/test_torch_op.py).  A handle is a plain int: the table below only maps it to the packed network
+# its caller created and will free.  The raw-weights ops above stay as the convenience form.
+# ---------------------------------------------------------------------------
+_HANDLES: Dict[int, object] = {}
+_HANDLE_IDS = itertools.count(1)
+
+
+def _from_handle(handle: int):
+    net = _HANDLES.get(int(handle))
+    if net is None:
+        raise ValueError(f"nnviterbi: {handle} is not a live handle of mlp_prepack (freed, or from another process)")
+    return net
+
+
+@torch.library.custom_op("nnviterbi::mlp_prepack", mutates_args=())
+def mlp_prepack(weights: List[torch.Tensor], biases: List[torch.Tensor], precision: str = "f32") -> int:
+    """Packs the network (``weights[l]`` [n_l, n_{l+1}], ``biases[l]`` [n_{l+1}], any device) for the CURRENT HIP
+    device and returns its handle.  Replaces building the TF variables + graph (src/fnn_viterbi.py:538-545) /
+    Saver.restore (mixed_snr:809-811).  ``precision``: "f32", "f16x3", or -- explicit opt-in outside the 1e-5 parity
+    contract, register-chained shapes only -- "f16".  The weights are COPIED: later edits of the tensors do not reach
+    the handle (pack again)."""
+    _require_cuda()
+    if len(weights) != len(biases) or not (2 <= len(weights) <= _cabi.NNV_WIDE_MAX_LAYERS):
+        raise ValueError("need 2..8 dense layers with one bias vector each")
+    precision = _resolve_precision(precision, allow_f16=True)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if precision == "f16":
+        net = PackedMLP(list(weights), list(biases), device=dev, precision="f16")
+    else:
+        net = _pack_any(list(weights), list(biases), dev, precision)
+    handle = next(_HANDLE_IDS)
+    _HANDLES[handle] = net
+    return handle
+
+
+@mlp_prepack.register_fake
+def _(weights, biases, precision="f32"):
+    raise RuntimeError("nnviterbi::mlp_prepack packs and uploads real weights: call it outside tracing / compilation "
+                       "and pass the handle in")
+
+
+@torch.library.custom_op("nnviterbi::mlp_free", mutates_args=())
+def mlp_free(handle: int) -> None:
+    """Releases the packed network (a synchronising hipFree: not inside a capture)."""
+    net = _HANDLES.pop(int(handle), None)
+    if net is not None:
+        net.close()
+
+
+@torch.library.custom_op("nnviterbi::mlp_decode_packed", mutates_args=(), device_types="cuda")
+def mlp_decode_packed(x: torch.Tensor, handle: int, tile_bits: int, labels: Optional[torch.Tensor] = None
+                      ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(cls int64 [N], bits uint8 [N, b], counters int64 [4]) like ``mlp_decode``, from a prepacked handle: THE HOT PATH
+    (src/fnn_viterbi.py:494-510,606-610,648-651) as launches on the current stream and nothing else."""
+    net = _from_handle(handle)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != net.n_input:
+        raise ValueError(f"x must be float32 [N, {net.n_input}]")
+    if tile_bits < 1 or tile_bits > 30 or (1 << tile_bits) < net.n_classes:
+        raise ValueError("tile_bits must satisfy 2**tile_bits >= n_classes")
+    if labels is not None and (labels.dtype != torch.int32 or tuple(labels.shape) != (x.shape[0],)):
+        raise ValueError("labels must be int32 [N] on x's device")
+    return _decode_with(net, x, tile_bits, labels)
+
+
+@mlp_decode_packed.register_fake
+def _(x, handle, tile_bits, labels=None):
+    n = x.shape[0]
+    return (x.new_empty((n,), dtype=torch.int64), x.new_empty((n, tile_bits), dtype=torch.uint8),
+            x.new_empty((4,), dtype=torch.int64))
+
+
+@torch.library.custom_op("nnviterbi::mlp_forward_packed", mutates_args=(), device_types="cuda")
+def mlp_forward_packed(x: torch.Tensor, handle: int) -> torch.Tensor:
+    """multilayer_perceptron(x, weights, biases) (src/fnn_viterbi.py:471-510) from a prepacked handle: the tanh'd class
+    layer [N, n_classes] float32 (debug / parity op)."""
+    net = _from_handle(handle)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != net.n_input:
+        raise ValueError(f"x must be float32 [N, {net.n_input}]")
+    if isinstance(net, PackedMLP):
+        return net.forward(x)
+    return net.decode(x if x.is_contiguous() else x.contiguous(), want_act=True)["act"]
+
+
+@mlp_forward_packed.register_fake
+def _(x, handle):
+    return x.new_empty((x.shape[0], _from_handle(handle).n_classes), dtype=torch.float32)

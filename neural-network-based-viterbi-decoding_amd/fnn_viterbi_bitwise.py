@@ -166,22 +166,17 @@ def _run(x, weights, biases, want_act=False, want_cls64=False):
     two launches of the layer-at-a-time path); wider
     first layers go through ``decoder.WideMLP(activation="relu")``."""
     import torch
-    from .decoder import BitwiseBank, WideMLP
+    from .decoder import BitwiseBank, WideMLP, cached_network
     xd = torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32)).cuda()
     Ws, bs = active_layers(weights, biases)
+    # the packed network stays in decoder.cached_network while calls keep coming with the same weights (one prepack)
     if np.asarray(Ws[0]).shape[1] <= 32 and np.asarray(Ws[0]).shape[0] % 2 == 0:
-        bank = BitwiseBank([(Ws[0], bs[0], Ws[1], bs[1])])
-        try:
-            r = bank.decode(xd, want_act=want_act)
-            return {"cls32": r["bits"][0].to(torch.int32), "cls64": r["bits"][0].to(torch.int64) if want_cls64 else None,
-                    "act": None if r["act"] is None else r["act"][0]}
-        finally:
-            bank.close()
-    net = WideMLP(Ws, bs, activation="relu")
-    try:
-        return net.decode(xd, want_act=want_act, want_cls64=want_cls64)
-    finally:
-        net.close()
+        bank = cached_network("bank1", list(Ws) + list(bs), lambda: BitwiseBank([(Ws[0], bs[0], Ws[1], bs[1])]))
+        r = bank.decode(xd, want_act=want_act)
+        return {"cls32": r["bits"][0].to(torch.int32), "cls64": r["bits"][0].to(torch.int64) if want_cls64 else None,
+                "act": None if r["act"] is None else r["act"][0]}
+    net = cached_network("relu", list(Ws) + list(bs), lambda: WideMLP(Ws, bs, activation="relu"))
+    return net.decode(xd, want_act=want_act, want_cls64=want_cls64)
 
 
 def predict(test_encoded: np.ndarray, weights: Dict, biases: Dict) -> np.ndarray:
@@ -199,21 +194,19 @@ def predict_all_positions(test_encoded: np.ndarray, models, test_info: Optional[
     Returns ``predictions`` int64 [N, P] (column p = what ``predict`` returns for network p) and,
     with ``test_info`` [N, L] and ``bit_positions`` (default 0..P-1), the error rate per position."""
     import torch
-    from .decoder import BitwiseBank
-    bank = BitwiseBank([(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models])
-    try:
-        xd = torch.from_numpy(np.ascontiguousarray(np.asarray(test_encoded), dtype=np.float32)).cuda()
-        labels = None
-        if test_info is not None:
-            pos = np.arange(len(models)) if bit_positions is None else np.asarray(bit_positions)
-            labels = torch.from_numpy(np.ascontiguousarray(np.asarray(test_info)[:, pos].T.astype(np.uint8))).cuda()
-        r = bank.decode(xd, labels=labels)
-        preds = r["bits"].cpu().numpy().T.astype(np.int64)
-        if labels is None:
-            return preds
-        return preds, r["errors"].cpu().numpy() / max(1, preds.shape[0])
-    finally:
-        bank.close()
+    from .decoder import BitwiseBank, cached_network
+    tuples = [(w["h1"], b["b1"], w["out"], b["out"]) for w, b in models]
+    bank = cached_network("bank", [a for t in tuples for a in t], lambda: BitwiseBank(tuples), extra=(len(tuples),))
+    xd = torch.from_numpy(np.ascontiguousarray(np.asarray(test_encoded), dtype=np.float32)).cuda()
+    labels = None
+    if test_info is not None:
+        pos = np.arange(len(models)) if bit_positions is None else np.asarray(bit_positions)
+        labels = torch.from_numpy(np.ascontiguousarray(np.asarray(test_info)[:, pos].T.astype(np.uint8))).cuda()
+    r = bank.decode(xd, labels=labels)
+    preds = r["bits"].cpu().numpy().T.astype(np.int64)
+    if labels is None:
+        return preds
+    return preds, r["errors"].cpu().numpy() / max(1, preds.shape[0])
 
 
 def save_model(path: str, weights: Dict, biases: Dict) -> str:

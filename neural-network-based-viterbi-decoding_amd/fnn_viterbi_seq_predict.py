@@ -165,27 +165,29 @@ def build_network(x, config: SequentialDecoderConfig, weights: Optional[Dict] = 
     output = None
     if x is not None:
         import torch
-        from .decoder import WideMLP
-        net = WideMLP(*weights_as_lists(weights, biases))
-        try:
-            xd = torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32)).cuda()
-            output = net.decode(xd, want_act=True)["act"].cpu().numpy()
-        finally:
-            net.close()
+        xd = torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32)).cuda()
+        output = _decoder_for(weights, biases).decode(xd, want_act=True)["act"].cpu().numpy()
     return output, weights, biases
+
+
+def _decoder_for(weights: Dict, biases: Dict, device=None):
+    """The packed sliding-window network, kept by ``decoder.cached_network`` while calls keep coming with the same
+    weights (3.4 MB packed twice -- layered + K6 -- and uploaded ONCE, not around every call).  Never closed here."""
+    import torch
+    from .decoder import WideMLP, _require_cuda, cached_network
+    _require_cuda()
+    Ws, bs = weights_as_lists(weights, biases)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        return cached_network("tanh", list(Ws) + list(bs), lambda: WideMLP(Ws, bs, device=dev))
 
 
 def predict_stream(coded_seq: np.ndarray, n_instances: int, weights: Dict, biases: Dict) -> np.ndarray:
     """``predictions_tensor.eval({x: test_data})`` for test_data = the first ``n_instances``
     windows of ``coded_seq`` (src/fnn_viterbi_seq_predict.py:507-524,592-611), int64."""
     import torch
-    from .decoder import WideMLP
-    net = WideMLP(*weights_as_lists(weights, biases))
-    try:
-        stream = torch.from_numpy(np.ascontiguousarray(np.asarray(coded_seq)[0], dtype=np.float32)).cuda()
-        return net.decode_stream(stream, n_instances, want_cls64=True)["cls64"].cpu().numpy()
-    finally:
-        net.close()
+    stream = torch.from_numpy(np.ascontiguousarray(np.asarray(coded_seq)[0], dtype=np.float32)).cuda()
+    return _decoder_for(weights, biases).decode_stream(stream, n_instances, want_cls64=True)["cls64"].cpu().numpy()
 
 
 def generate_test_stream_on_device(n_info_bits: int, sigma: float, seed: int, device=None):
@@ -209,18 +211,13 @@ def evaluate_stream_on_device(weights: Dict, biases: Dict, n_info_bits: int, sig
     """Generate a test stream on the GPU and decode every full window of it (window i = coded[2i : 2i + window] decides
     info bit i, :293-336) in one persistent launch; returns the error count and rate over the decodable bits."""
     import torch
-    from .decoder import WideMLP
     Ws, bs = weights_as_lists(weights, biases)
     window = int(np.asarray(Ws[0]).shape[0]) if window_length is None else int(window_length)
     info, coded = generate_test_stream_on_device(n_info_bits, sigma, seed, device=device)
     n_instances = (coded.numel() - window) // 2 + 1
     if n_instances < 1:
         raise ValueError("the stream is shorter than one window")
-    net = WideMLP(Ws, bs, device=coded.device)
-    try:
-        pred = net.decode_stream(coded, n_instances)["cls32"]
-    finally:
-        net.close()
+    pred = _decoder_for(weights, biases, device=coded.device).decode_stream(coded, n_instances)["cls32"]
     errors = int((pred != info[:n_instances].to(torch.int32)).sum().item())
     return {"decoded_bits": n_instances, "bit_errors": errors, "ber": errors / n_instances}
 

@@ -179,32 +179,35 @@ def run_seq2seq(model: Dict, feeds: Dict, n_bits: Optional[int] = None, info_bit
     (argmax over the size-1 vocabulary axis: zeros), and, as an extension, ``hard_bits`` uint8
     [B, n_bits] (logit > 0) with error ``counters`` against ``info_bits01`` [B, n_bits] if given."""
     import torch
-    from .decoder import Seq2SeqLSTM
+    from .decoder import Seq2SeqLSTM, _require_cuda, cached_network
+    _require_cuda()                      # no CPU path: fails loudly (NNViterbiError) without an MI355X
     cfg = model["config"]
     enc = _time_major(feeds["encoder_inputs"])
     dec = _time_major(feeds["decoder_inputs"])
     n_bits = cfg.block_length if n_bits is None else int(n_bits)
-    net = Seq2SeqLSTM(model["params"], forget_bias=model.get("forget_bias", 1.0), device=device,
-                      precision=precision)     # "f16x3": hi/lo f16 operands, ~2x, same 5e-5 tolerance
-    try:
-        dev = net.device
-        info = None
-        if info_bits01 is not None:
-            info = torch.from_numpy(np.ascontiguousarray(np.asarray(info_bits01, np.uint8).T)).to(dev)
-        r = net.forward(torch.from_numpy(enc).to(dev), torch.from_numpy(dec).to(dev),
-                        info_bits=info, n_bits=n_bits, want_bits=True)
-        torch.cuda.synchronize(dev)
-        logits = r["logits"].cpu().numpy()
-        out = {
-            "decoder_logits": logits,
-            "decoder_prediction": np.zeros(logits.shape, np.int64),   # argmax over one logit (:321)
-            "hard_bits": np.ascontiguousarray(r["bits"].cpu().numpy().T),
-        }
-        if r["counters"] is not None:
-            out["counters"] = r["counters"].cpu().numpy()
-        return out
-    finally:
-        net.close()
+    keys = ("enc_kernel", "enc_bias", "dec_kernel", "dec_bias", "proj_w", "proj_b")
+    fb = float(model.get("forget_bias", 1.0))
+    dev0 = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev0):     # kept while calls keep coming with the same parameters: one prepack, never closed here
+        net = cached_network("seq2seq", [model["params"][k] for k in keys],
+                             lambda: Seq2SeqLSTM(model["params"], forget_bias=fb, device=dev0, precision=precision),
+                             extra=(fb, precision))     # "f16x3": hi/lo f16 operands, ~2x, same 5e-5 tolerance
+    dev = net.device
+    info = None
+    if info_bits01 is not None:
+        info = torch.from_numpy(np.ascontiguousarray(np.asarray(info_bits01, np.uint8).T)).to(dev)
+    r = net.forward(torch.from_numpy(enc).to(dev), torch.from_numpy(dec).to(dev),
+                    info_bits=info, n_bits=n_bits, want_bits=True)
+    torch.cuda.synchronize(dev)
+    logits = r["logits"].cpu().numpy()
+    out = {
+        "decoder_logits": logits,
+        "decoder_prediction": np.zeros(logits.shape, np.int64),   # argmax over one logit (:321)
+        "hard_bits": np.ascontiguousarray(r["bits"].cpu().numpy().T),
+    }
+    if r["counters"] is not None:
+        out["counters"] = r["counters"].cpu().numpy()
+    return out
 
 
 # ==============================================================================

@@ -141,17 +141,21 @@ class TFAdam:
 
     @torch.no_grad()
     def step(self) -> None:
-        grads = [p.grad for p in self.params]
+        # variables the loss does not reach have no gradient and are left alone (as minimize() leaves them)
+        live = [i for i, p in enumerate(self.params) if p.grad is not None]
+        params = [self.params[i] for i in live]
+        grads = [self.params[i].grad for i in live]
+        m, v = [self.m[i] for i in live], [self.v[i] for i in live]
         self.beta1_power.mul_(self.beta1)
         self.beta2_power.mul_(self.beta2)
         lr_t = self.lr * torch.sqrt(1.0 - self.beta2_power) / (1.0 - self.beta1_power)
-        torch._foreach_lerp_(self.m, grads, 1.0 - self.beta1)                 # m += (g - m)(1 - beta1)
-        torch._foreach_lerp_(self.v, torch._foreach_mul(grads, grads), 1.0 - self.beta2)
-        denom = torch._foreach_sqrt(self.v)
+        torch._foreach_lerp_(m, grads, 1.0 - self.beta1)                      # m += (g - m)(1 - beta1)
+        torch._foreach_lerp_(v, torch._foreach_mul(grads, grads), 1.0 - self.beta2)
+        denom = torch._foreach_sqrt(v)
         torch._foreach_add_(denom, self.eps)
-        upd = torch._foreach_div(self.m, denom)
+        upd = torch._foreach_div(m, denom)
         torch._foreach_mul_(upd, lr_t)
-        torch._foreach_sub_(self.params, upd)
+        torch._foreach_sub_(params, upd)
 
 
 class FNNTrainer:

@@ -414,3 +414,59 @@ def test_sliding_window_stream_generated_and_decoded_on_the_device(cuda_device):
     assert 0.0 <= r["ber"] <= 1.0
     with pytest.raises(ValueError):
         sq.evaluate_stream_on_device(w, b, 64, sigma, seed)          # 128 symbols: shorter than one 200-symbol window
+
+
+# ------------------------------------------------ block_length 13 and 15: the sizes the reference's own tests touch
+@pytest.mark.parametrize("b,n", [(13, 2999), (15, 1031), (16, 257)])
+def test_decoder_config_block_lengths_beyond_twelve(cuda_device, b, n):
+    """The reference's DecoderConfig is exercised up to block_length 15 in its own tests (tests/test_utilities.py:
+    342-348: n_input 30, 32768 classes; src/fnn_viterbi.py:65-73).  From n_in = 26 / 8192 classes on the network goes
+    through the wide path's layer-at-a-time kernels (class layer 32 -> 2^b as one fp32-MFMA GEMM launch, argmax fused
+    into its epilogue).  Through ``fnn_viterbi.predict`` / ``multilayer_perceptron`` AND the torch ops, ragged
+    row counts, against the float64 restatement under the 1e-5 rule; counters exact functions of the classes.
+    2^16 classes is the header's stated limit (NNV_WIDE_MAX_CLASSES); beyond it prepack refuses, loudly."""
+    from nnviterbi_amd import decoder
+    cfg = fv.DecoderConfig(block_length=b)
+    assert (cfg.n_input, cfg.n_classes) == (2 * b, 2 ** b)
+    w, bd = fv.initialize_weights(cfg, rng=np.random.RandomState(b))
+    bd = {k: (np.random.RandomState(b + 1).randn(*v.shape) * 0.1).astype(np.float32) for k, v in bd.items()}
+    Ws, bs = fv.weights_as_lists(w, bd)
+    rng = np.random.RandomState(100 + b)
+    cb = fv.generate_class_bits(b)
+    labels = rng.randint(0, 2 ** b, n).astype(np.int32)
+    x = (np.where(fv.encode_133171_batch(cb[labels]) == 1, 1.0, -1.0) + cfg.sigma * rng.randn(n, 2 * b)).astype(np.float32)
+    c64, _, o64 = O.decode(x, Ws, bs, b, np.float64)
+    margin = O.top2_margin(o64)
+    decoder.clear_pack_cache()
+    # reference-shaped calls
+    preds, counters = fv.predict(x, w, bd, labels=labels, tile_bits=b)
+    assert preds.dtype == np.int64 and preds.shape == (n,)
+    bad = preds != c64
+    assert not bad.any() or margin[bad].max() < TOL
+    assert np.array_equal(counters, O.error_counters(preds, labels, b))
+    out = fv.multilayer_perceptron(x[:201], w, bd)
+    assert out.shape == (201, 2 ** b) and np.abs(out - o64[:201]).max() < TOL
+    # torch ops: raw weights and prepacked handle
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda()
+    Wt = [torch.from_numpy(a).cuda() for a in Ws]
+    bt = [torch.from_numpy(a).cuda() for a in bs]
+    cls, bits, cnt = torch.ops.nnviterbi.mlp_decode(xd, Wt, bt, b, ld)
+    assert np.array_equal(cls.cpu().numpy(), preds)
+    assert np.array_equal(bits.cpu().numpy(), O.class_to_bits(preds, b))
+    assert np.array_equal(cnt.cpu().numpy(), O.error_counters(preds, labels, b))
+    h = torch.ops.nnviterbi.mlp_prepack(Wt, bt, "f32")
+    cls2, _, cnt2 = torch.ops.nnviterbi.mlp_decode_packed(xd, h, b, ld)
+    assert torch.equal(cls2, cls) and torch.equal(cnt2, cnt)
+    torch.ops.nnviterbi.mlp_free(h)
+    decoder.clear_pack_cache()
+
+
+def test_class_layers_beyond_the_stated_limit_are_refused(cuda_device):
+    Ws = [np.zeros((34, 32), np.float32), np.zeros((32, 2 ** 17), np.float32)]
+    bs = [np.zeros(32, np.float32), np.zeros(2 ** 17, np.float32)]
+    with pytest.raises(Exception, match="unsupported"):
+        WideMLP(Ws, bs)
+    Ws = [np.zeros((20000, 32), np.float32), np.zeros((32, 4), np.float32)]
+    bs = [np.zeros(32, np.float32), np.zeros(4, np.float32)]
+    with pytest.raises(Exception, match="unsupported"):
+        WideMLP(Ws, bs)

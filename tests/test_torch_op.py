@@ -341,3 +341,160 @@ def test_op_under_graph_capture_says_what_to_do_instead(cuda_device):
     assert torch.equal(out, eager)
     net.close()
     decoder.clear_pack_cache()
+
+
+# ---------------------------------------------------------------- handle-based ops + the reference-shaped calls' cache
+def test_cached_network_is_keyed_by_the_bytes(monkeypatch):
+    """decoder.cached_network (what fnn_viterbi.predict / run_graph / predict_stream ... keep their packed network in):
+    the same BYTES find the same network whatever array objects carry them, an in-place edit does not, and the
+    least-recently-used entry is closed when the cache is full.  No GPU: `build` is a stand-in."""
+    monkeypatch.setattr(decoder, "_require_cuda", lambda: None)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    decoder.clear_pack_cache()
+
+    class Net:
+        def __init__(self):
+            self.closed = False
+
+        def close(self):
+            self.closed = True
+
+    made = []
+
+    def build():
+        made.append(Net())
+        return made[-1]
+
+    w = [np.arange(12, dtype=np.float32).reshape(3, 4), np.ones(4, np.float32)]
+    a = decoder.cached_network("ff", w, build)
+    assert decoder.cached_network("ff", [w[0].copy(), w[1].astype(np.float64)], build) is a and len(made) == 1
+    assert decoder.cached_network("ff", w, build, extra=("relu",)) is not a         # another kind of network
+    assert decoder.cached_network("ff", [w[0].reshape(4, 3), w[1]], build) is not a   # same bytes, another shape
+    w[0][0, 0] = 99.0                                                               # edited in place
+    b = decoder.cached_network("ff", w, build)
+    assert b is not a and len(made) == 4
+    for i in range(decoder._NET_CACHE_MAX):
+        decoder.cached_network("ff", [np.full(3, float(i), np.float32)], build)
+    assert a.closed and not made[-1].closed                                         # oldest evicted and closed
+    decoder.clear_pack_cache()
+    assert all(n.closed for n in made) and not decoder._NET_CACHE
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,b,precision", [([16, 128, 64, 32, 256], 8, "f32"), ([16, 128, 64, 32, 256], 8, "f16x3"),
+                                              ([20, 128, 64, 1024], 10, "f32"), ([14, 200, 96, 48, 128], 7, "f32"),
+                                              ([40, 100, 100, 100, 100, 2], 1, "f32")])
+def test_prepacked_handle_ops_equal_the_raw_weight_ops_and_capture_into_a_hip_graph(cuda_device, dims, b, precision):
+    """SURVEY 8(b) "stream-ordered, re-entrant, no global state": nnviterbi::mlp_prepack once, then
+    nnviterbi::mlp_decode_packed is launches on the current stream and nothing else -- so it captures into a HIP graph
+    (a capture forbids host waits and hipMalloc) WITHOUT a warm-up call, and the replays on new inputs equal the eager
+    raw-weights op, classes, bits and counters.  K1 shapes (resident and streamed class layer), K6 and a deep net."""
+    rng = np.random.RandomState(sum(dims) + b)
+    Ws = [(rng.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+    bs = [(rng.randn(d) * 0.1).astype(np.float32) for d in dims[1:]]
+    n = 5003
+    xs = [torch.from_numpy(rng.randn(n, dims[0]).astype(np.float32)).cuda() for _ in range(3)]
+    labs = [torch.from_numpy(rng.randint(0, dims[-1], n).astype(np.int32)).cuda() for _ in range(3)]
+    decoder.clear_pack_cache()
+    decoder.set_default_precision(precision)
+    try:
+        before = dict(decoder.PACK_STATS)
+        h = torch.ops.nnviterbi.mlp_prepack(_t(Ws, "cuda"), _t(bs), precision)      # weights from any device
+        assert isinstance(h, int) and sum(decoder.PACK_STATS.values()) == sum(before.values()) + 1
+        x_static, l_static = xs[0].clone(), labs[0].clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):                                                   # first call ever on this handle
+            cls, bits, cnt = torch.ops.nnviterbi.mlp_decode_packed(x_static, h, b, l_static)
+        for x, lab in zip(xs, labs):
+            x_static.copy_(x)
+            l_static.copy_(lab)
+            g.replay()
+            torch.cuda.synchronize()
+            e_cls, e_bits, e_cnt = torch.ops.nnviterbi.mlp_decode(x, _t(Ws, "cuda"), _t(bs, "cuda"), b, lab)
+            assert torch.equal(cls, e_cls) and torch.equal(bits, e_bits) and torch.equal(cnt, e_cnt)
+            p_cls, p_bits, p_cnt = torch.ops.nnviterbi.mlp_decode_packed(x, h, b, lab)     # eager, same handle
+            assert torch.equal(p_cls, e_cls) and torch.equal(p_bits, e_bits) and torch.equal(p_cnt, e_cnt)
+        # 20 more decodes: no further prepack (the raw-weights op packed once for its own cache)
+        count = sum(decoder.PACK_STATS.values())
+        for _ in range(20):
+            torch.ops.nnviterbi.mlp_decode_packed(xs[1], h, b, None)
+        assert sum(decoder.PACK_STATS.values()) == count
+        out = torch.ops.nnviterbi.mlp_forward_packed(xs[2], h)
+        assert torch.equal(out, torch.ops.nnviterbi.mlp_forward(xs[2], _t(Ws, "cuda"), _t(bs, "cuda")))
+        o64 = O.decode(xs[2].cpu().numpy(), Ws, bs, b, np.float64)[2]
+        assert np.abs(out.cpu().numpy() - o64).max() < TOL
+        with pytest.raises(Exception):
+            torch.ops.nnviterbi.mlp_decode_packed(xs[0][:, :-1].contiguous(), h, b, None)   # wrong row length
+        with pytest.raises(Exception):
+            torch.ops.nnviterbi.mlp_decode_packed(xs[0], h, b, labs[0].to(torch.int64))
+        torch.ops.nnviterbi.mlp_free(h)
+        with pytest.raises(Exception, match="not a live handle"):
+            torch.ops.nnviterbi.mlp_decode_packed(xs[0], h, b, None)
+        torch.ops.nnviterbi.mlp_free(h)                                              # idempotent
+    finally:
+        decoder.set_default_precision("f32")
+        decoder.clear_pack_cache()
+
+
+@pytest.mark.gpu
+def test_two_handles_on_two_streams_do_not_share_state(cuda_device):
+    """Re-entrant: two networks, two streams, interleaved launches; each result equals its own network's."""
+    rng = np.random.RandomState(77)
+    dims = [16, 128, 64, 32, 256]
+    nets = []
+    for _ in range(2):
+        Ws = [(rng.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(4)]
+        bs = [(rng.randn(d) * 0.1).astype(np.float32) for d in dims[1:]]
+        nets.append((Ws, bs, torch.ops.nnviterbi.mlp_prepack(_t(Ws), _t(bs), "f32")))
+    x = torch.from_numpy(rng.randn(200_003, 16).astype(np.float32)).cuda()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    got = [[], []]
+    for _ in range(4):
+        for i, (_, _, h) in enumerate(nets):
+            with torch.cuda.stream(streams[i]):
+                got[i].append(torch.ops.nnviterbi.mlp_decode_packed(x, h, 8, None)[0])
+    torch.cuda.synchronize()
+    for i, (Ws, bs, h) in enumerate(nets):
+        want = torch.ops.nnviterbi.mlp_decode(x, _t(Ws, "cuda"), _t(bs, "cuda"), 8)[0]
+        assert all(torch.equal(c, want) for c in got[i])
+        torch.ops.nnviterbi.mlp_free(h)
+    assert not torch.equal(got[0][0], got[1][0])
+    decoder.clear_pack_cache()
+
+
+@pytest.mark.gpu
+def test_reference_shaped_calls_pack_once(cuda_device, capsys, tmp_path):
+    """fnn_viterbi.predict / multilayer_perceptron / run_graph packed, uploaded and freed the
+    network around every call.  Now 50 x run_graph(model) on the same restored model = ONE prepack; new weights = one
+    more; and the predictions are the same as a fresh pack's."""
+    from nnviterbi_amd import fnn_viterbi as fv
+    from nnviterbi_amd import fnn_viterbi_mixed_snr as mx
+    cfg = mx.MixedSNRDecoderConfig(block_length=7, samples_per_class_train=2, samples_per_class_test=20)
+    np.random.seed(4)
+    tr, te, trl, rl, rt, _ = mx.get_dataset(cfg)
+    tel = mx.create_one_hot_labels(mx.get_dataset.last_test_labels, cfg.n_classes)
+    w, b = mx.initialize_weights(cfg, rng=np.random.RandomState(1))
+    path = mx.save_model(str(tmp_path / "m"), w, b)
+    decoder.clear_pack_cache()
+    model = mx.create_model_graph(cfg, tr, trl, te, tel, train_mode=False, model_load_path=path, run=False)
+    base = sum(decoder.PACK_STATS.values())
+    first = mx.run_graph(model).copy()
+    assert sum(decoder.PACK_STATS.values()) == base + 1
+    for _ in range(49):
+        assert np.array_equal(mx.run_graph(model), first)
+    for _ in range(5):
+        fv.predict(te, model.weights, model.biases)
+        fv.multilayer_perceptron(te[:100], model.weights, model.biases)
+    assert sum(decoder.PACK_STATS.values()) == base + 1          # 50 run_graph + 10 direct calls: one prepack
+    net = decoder.PackedMLP(*fv.weights_as_lists(model.weights, model.biases))
+    assert np.array_equal(net.decode(torch.from_numpy(te).cuda(), want_cls64=True)["cls64"].cpu().numpy(), first)
+    net.close()
+    w2 = {k: v + np.float32(0.01) for k, v in model.weights.items()}
+    fv.predict(te, w2, model.biases)
+    assert sum(decoder.PACK_STATS.values()) == base + 3          # the explicit PackedMLP above + the new weights
+    model.weights["h1"][0, 0] += 1.0                             # in-place edit of the model's own arrays: seen
+    changed = mx.run_graph(model)
+    assert sum(decoder.PACK_STATS.values()) == base + 4 and changed.shape == first.shape
+    capsys.readouterr()
+    decoder.clear_pack_cache()

@@ -144,3 +144,12 @@ def test_dropout_draws_bernoulli_keep_prob_and_eval_has_none():
     c = tr.forward(xb, True)
     e1, e2 = tr.forward(xb, False), tr.forward(xb, False)
     assert not torch.equal(a, c) and torch.equal(e1, e2)
+
+
+def test_tfadam_leaves_variables_without_a_gradient_alone():
+    a = torch.tensor([1.0], requires_grad=True)
+    b = torch.tensor([2.0], requires_grad=True)
+    opt = training.TFAdam([a, b], lr=0.1)
+    (a * 3.0).sum().backward()
+    opt.step()
+    assert float(b.detach()) == 2.0 and abs(float(a.detach()) - 0.9) < 1e-6
