@@ -1,7 +1,10 @@
 #!/bin/bash
 # Usage: tools/build_variant.sh <name> [extra hipcc flags...]
 # Builds neural-network-based-viterbi-decoding_amd/ab_<name>.so from the current sources with extra
-# flags (e.g. -DNNV_DEFER_ARGMAX=0) in a scratch object directory; for tools/ab_bench.sh A/B runs.
+# flags in a scratch object directory; for tools/ab_bench.sh A/B runs.  These side libraries are the ONLY builds with
+# -DNNV_AB_BUILD: there nnv::ab_env() reads the tuning overrides (NNV_THREADS, NNV_BAND_RESIDENT_512, NNV_NO_LEAN,
+# NNV_STREAM_MAX_RESIDENT, NNV_FUSED_WAVES, NNV_BANK_GROUP, NNV_DENSE_BK64, NNV_DENSE16_BK32, NNV_HOST_THREADS) and
+# -DNNV_DIAG enables K1's per-phase stamps.  libnnviterbi_hip.so (csrc/Makefile) has none of it.
 # NNV_F32_SCHED="" builds the fp32 K1 kernels with the default scheduler instead of max-ilp.
 set -e
 name=$1; shift
@@ -19,7 +22,7 @@ for f in nnv_mlp_decode_f32 nnv_mlp_decode_f16x3 nnv_mlp_launch nnv_generator nn
   [ $f = nnv_bitwise_single ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
   [ $f = nnv_mlp_decode_f32 ] && { srcf=nnv_mlp_decode; extra="-DNNV_TU_PREC=0 ${NNV_F32_SCHED--mllvm -amdgpu-sched-strategy=max-ilp}"; }
   [ $f = nnv_mlp_decode_f16x3 ] && { srcf=nnv_mlp_decode; extra="-DNNV_TU_PREC=1"; }
-  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$here/include -I$src -Wall -Wno-unused-result $extra "$@" -c $src/$srcf.hip -o $obj/$f.o &
+  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DNNV_AB_BUILD -I$here/include -I$src -Wall -Wno-unused-result $extra "$@" -c $src/$srcf.hip -o $obj/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
