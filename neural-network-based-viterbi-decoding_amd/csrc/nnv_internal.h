@@ -142,7 +142,7 @@ struct DecodeParams {
 };
 
 // K1 variants (template parameter VARIANT of mlp_decode_kernel; see nnv_mlp_decode.hip)
-constexpr int kVarGeneral = 0, kVarStream = 1, kVarLean = 2;
+constexpr int kVarGeneral = 0, kVarStream = 1, kVarLean = 2, kVarLeanBins = 3;
 // The running argmax winner's 16 raw accumulators are parked in a per-lane LDS slot by exec-masked
 // ds_write_b128 (no VALU) instead of 16 v_cndmask per class tile: 64 bytes per thread, reserved by decode_plan.
 constexpr int kKeepSlotBytes = 64;

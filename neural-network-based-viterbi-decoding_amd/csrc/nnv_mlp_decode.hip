@@ -293,10 +293,13 @@ __device__ unsigned long long g_diag[16];
 //   kVarLean     the benchmark / sweep call shape only: 16-byte aligned rows of an even, 4-divisible
 //                half width (p.xvec), class count a multiple of 32, classes + counters out (no
 //                int64 classes, no bit matrix, no per-SNR bins), class layer resident
+//   kVarLeanBins the lean variant WITH per-SNR-bin counters: the mixed-SNR sweep's call shape (BASELINE
+//                configs[3], nnv_mlp_decode_binned_f32 on aligned rows); round 5: it ran the general variant
 template <int PREC, int G1, int NHID, int MTA, int MTB, int MTC, int NT, bool WRITE_ACT, int VARIANT>
 __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   constexpr bool STREAM = VARIANT == kVarStream;
-  constexpr bool LEAN = VARIANT == kVarLean;
+  constexpr bool LEAN = VARIANT == kVarLean || VARIANT == kVarLeanBins;
+  constexpr bool BINS = VARIANT != kVarLean;   // per-SNR-bin counters compiled in
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // layer 1: fp32 G1 groups of 4 steps (2 inputs each); f16x3 KS1 k-steps of 16 inputs
   constexpr int KS1 = (G1 + 1) / 2;
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       }
       if (p.labels) {
         const unsigned diff = static_cast<unsigned>(bidx) ^ static_cast<unsigned>(label);
-        if (!LEAN && p.n_bins > 1) {  // per-SNR-bin counters (mixed-SNR sweep): LDS atomics
+        if (BINS && p.n_bins > 1) {  // per-SNR-bin counters (mixed-SNR sweep): LDS atomics
           const int bin = static_cast<int>(((p.first_row + row) / p.rows_per_block) % p.n_bins);
           atomicAdd(bin_ctr + 4 * bin + 0, static_cast<unsigned>(__builtin_popcount(diff)));
           atomicAdd(bin_ctr + 4 * bin + 1, diff != 0u ? 1u : 0u);
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #endif
 
   // ---------------- error counters: one atomic pair per wave --------------
-  if (!LEAN && p.counters && p.n_bins > 1) {
+  if (BINS && p.counters && p.n_bins > 1) {
     __syncthreads();
     if (threadIdx.x < p.n_bins) {
       const unsigned *c = bin_ctr + 4 * threadIdx.x;
@@ -759,13 +762,13 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #error "compile with -DNNV_TU_PREC=0 (fp32 kernels) or 1 (f16x3 kernels); see csrc/Makefile"
 #endif
 
-// decode kernels come in three variants (see the kernel); the debug (ACT) ones only as kVarStream
+// decode kernels come in four variants (see the kernel); the debug (ACT) ones only as kVarStream
 #define NNV_K1(P, G1, NHID, A, B, C, NT, ACT, ST) \
   { P, G1, NHID, A, B, C, NT, ACT, ST, mlp_decode_kernel<P, G1, NHID, A, B, C, NT, ACT, ST> }
 #define NNV_K(P, G1, NHID, A, B, C, NT, ACT) NNV_K_##ACT(P, G1, NHID, A, B, C, NT)
 #define NNV_K_false(P, G1, NHID, A, B, C, NT)                                                         \
   NNV_K1(P, G1, NHID, A, B, C, NT, false, kVarGeneral), NNV_K1(P, G1, NHID, A, B, C, NT, false, kVarStream), \
-  NNV_K1(P, G1, NHID, A, B, C, NT, false, kVarLean)
+  NNV_K1(P, G1, NHID, A, B, C, NT, false, kVarLean), NNV_K1(P, G1, NHID, A, B, C, NT, false, kVarLeanBins)
 #define NNV_K_true(P, G1, NHID, A, B, C, NT) NNV_K1(P, G1, NHID, A, B, C, NT, true, kVarStream)
 
 // The reference's networks: hidden widths are the first NHID of (128, 64, 32)

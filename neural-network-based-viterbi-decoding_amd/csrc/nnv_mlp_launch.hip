@@ -22,11 +22,12 @@ int kernel_index(const KernelEntry *k) {
   return kNumKernelsF32 + static_cast<int>(k - kKernelsF16x3);
 }
 
-const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act, bool lean = false) {
+// lean: 0 general, 1 lean, 2 lean with per-SNR-bin counters (ignored for streamed / debug kernels)
+const KernelEntry *find_kernel(const PackedShape &s, int nt, bool act, int lean = 0) {
   const int mta = s.mt[0];
   const int mtb = s.nhid >= 2 ? s.mt[1] : 1;
   const int mtc = s.nhid >= 3 ? s.mt[2] : 1;
-  const int variant = (act || s.streams != 0) ? kVarStream : (lean ? kVarLean : kVarGeneral);
+  const int variant = (act || s.streams != 0) ? kVarStream : (lean == 2 ? kVarLeanBins : (lean == 1 ? kVarLean : kVarGeneral));
   const KernelEntry *tab = s.precision == kPrecF32 ? kKernelsF32 : kKernelsF16x3;  // second table: both 16-bit modes
   const int n = s.precision == kPrecF32 ? kNumKernelsF32 : kNumKernelsF16x3;
   for (int i = 0; i < n; ++i) {
@@ -73,7 +74,7 @@ nnv_status decode_supported(const PackedShape &s) {
 int decode_pick_threads(const PackedShape &s) { return pick_threads_impl(s); }
 
 int decode_kernel_vgprs(const PackedShape &s, int threads, bool lean) {
-  const KernelEntry *k = find_kernel(s, threads, false, lean);
+  const KernelEntry *k = find_kernel(s, threads, false, lean ? 1 : 0);
   if (!k) return 0;
   hipFuncAttributes attr;
   if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k->fn)) != hipSuccess) return 0;
@@ -165,9 +166,9 @@ nnv_status decode_prepare(const PackedShape &s, int num_cus, int lds_limit, int 
   LaunchPlan plan;
   const nnv_status st = decode_plan(s, 1 << 20, num_cus, lds_limit, threads, &plan);
   if (st != NNV_OK) return st;
-  for (const int which : {0, 1, 2}) {  // decode, debug forward, lean decode
-    if (which == 2 && s.streams != 0) continue;
-    const KernelEntry *k = find_kernel(s, which == 1 ? 512 : plan.threads, which == 1, which == 2);
+  for (const int which : {0, 1, 2, 3}) {  // decode, debug forward, lean decode, lean decode with SNR bins
+    if (which >= 2 && s.streams != 0) continue;
+    const KernelEntry *k = find_kernel(s, which == 1 ? 512 : plan.threads, which == 1, which >= 2 ? which - 1 : 0);
     if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
     const nnv_status e = ensure_lds_optin(device, k, plan.lds_bytes);
     if (e != NNV_OK) return e;
@@ -180,9 +181,8 @@ nnv_status decode_launch(const PackedShape &s, const DecodeParams &p,
                          hipStream_t stream) {
   const int nt = write_act ? 512 : plan.threads;
   static const bool no_lean = ab_env("NNV_NO_LEAN") != nullptr;  // A/B builds only
-  const bool lean = !no_lean && s.streams == 0 && !write_act && p.xvec && p.n_bins == 1 && !p.bits && !p.cls64 &&
-                    p.n_classes % 32 == 0;
-  const KernelEntry *k = find_kernel(s, nt, write_act, lean);
+  const bool lean = !no_lean && s.streams == 0 && !write_act && p.xvec && !p.bits && !p.cls64 && p.n_classes % 32 == 0;
+  const KernelEntry *k = find_kernel(s, nt, write_act, lean ? (p.n_bins > 1 ? 2 : 1) : 0);
   if (!k) return NNV_ERR_UNSUPPORTED_SHAPE;
   const int lds_bytes = plan.lds_bytes;
   {
