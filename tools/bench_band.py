@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+# NOTE (round 5): NNV_BAND_RESIDENT_512 is read only by libraries built with tools/build_variant.sh (-DNNV_AB_BUILD);
+# point NNV_LIB at such a build -- the shipped libnnviterbi_hip.so reads no environment variable.
 """The 96-128 KB band of K1: a network that fits the LDS beside 512 threads' winner slots but not
 beside 1024 threads' -- e.g. 18->128->64->32->512 (120 KB packed).  Default: class layer streamed at 1024 threads;
 NNV_BAND_RESIDENT_512=1 (read once per process): the whole network resident at 512 threads instead.

@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+# NOTE (round 5): NNV_THREADS / -DNNV_DIAG is read only by libraries built with tools/build_variant.sh (-DNNV_AB_BUILD);
+# point NNV_LIB at such a build -- the shipped libnnviterbi_hip.so reads no environment variable.
 """Diagnostic only: per-phase s_memtime shares of (block 0, wave 0) from a -DNNV_DIAG build.
 Usage: NNV_LIB=.../ab_DIAG.so NNV_THREADS=256|512|1024 python tools/diag_stamps.py"""
 import ctypes, os, sys

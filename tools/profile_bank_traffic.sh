@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE (round 5): NNV_BANK_GROUP is read only by libraries built with tools/build_variant.sh (-DNNV_AB_BUILD);
+# point NNV_LIB at such a build -- the shipped libnnviterbi_hip.so reads no environment variable.
 # Runs ON the GPU box: L2 <- fabric bytes (FETCH_SIZE) of the bit-wise bank kernel per tile order.
 #   tools/profile_bank_traffic.sh <tag> [groups...]  -> gpurun_out/prof_<tag>/pmc_bank_g<G>/
 set -u
