@@ -470,3 +470,30 @@ def test_class_layers_beyond_the_stated_limit_are_refused(cuda_device):
     bs = [np.zeros(32, np.float32), np.zeros(4, np.float32)]
     with pytest.raises(Exception, match="unsupported"):
         WideMLP(Ws, bs)
+
+
+@pytest.mark.parametrize("activation", ["tanh", "relu"])
+@pytest.mark.parametrize("n_classes,n", [(65, 1000), (100, 129), (128, 4099), (129, 777), (500, 2000), (1000, 1), (4097, 513)])
+def test_fused_class_argmax_epilogue_equals_the_argmax_over_the_stored_row(cuda_device, n_classes, n, activation):
+    """Round 5: a wide class layer on the layer-at-a-time path keeps only (maximum, class) per row and 128-column block
+    (dense_tanh_kernel<.., CLS>) and merges them (partial_argmax_kernel); with the debug output requested the same call
+    stores the activated row and scans it (row_argmax_kernel).  Same values, same first-maximum rule: the classes must be
+    IDENTICAL, padding columns (act(0) = 0 would beat negative outputs) must never win, and both equal np.argmax of the
+    stored outputs.  ReLU makes exact ties at 0.0 common: the lowest class index wins in both."""
+    dims = [24, 40, n_classes]
+    Ws, bs = _net(dims, n_classes, bias_scale=0.3)
+    if activation == "tanh":
+        bs[-1] = bs[-1] - 2.0                      # most outputs negative: a padding column's tanh(0) = 0 would win if unmasked
+    net = WideMLP(Ws, bs, activation=activation, chunk_rows=512)
+    net.set_path("layered")
+    x = torch.from_numpy(np.random.RandomState(n).randn(n, dims[0]).astype(np.float32)).cuda()
+    fused = net.decode(x, want_cls64=True)                   # argmax in the GEMM epilogue
+    stored = net.decode(x, want_act=True, want_cls64=True)   # activated rows stored, then scanned
+    assert torch.equal(fused["cls32"], stored["cls32"]) and torch.equal(fused["cls64"], stored["cls64"])
+    act = stored["act"].cpu().numpy()
+    assert np.array_equal(fused["cls32"].cpu().numpy(), act.argmax(axis=1))
+    assert int(fused["cls32"].max()) < n_classes
+    c64, _, o64 = O.decode(x.cpu().numpy(), Ws, bs, 1, np.float64, activation=activation)
+    bad = fused["cls32"].cpu().numpy() != c64
+    assert not bad.any() or O.top2_margin(o64)[bad].max() < TOL * max(1.0, np.abs(o64).max())
+    net.close()
