@@ -93,6 +93,60 @@ def test_counter_reduction_equals_single_rank(tmp_path, world):
     assert full[3] == N_BLOCKS * ROWS_PER_BLOCK and full[2] == full[3] * B
 
 
+# ---- BASELINE configs[3]'s shape: block i at SNR bin i % n_bins, per-bin counters [n_bins, 4], one all-reduce ----
+N_BINS, BIN_SIGMAS = 7, [0.7, 0.65, 0.6, 0.55, 0.5, 0.45, 0.4]
+
+
+def _binned_counters_for(first_block, n_blocks):
+    """What distributed.decode_blocks_sharded + nnv_mlp_decode_binned_f32 compute for a shard, restated with the oracle:
+    row r -> block (first_row + r) // rows_per_block -> bin block % n_bins; the generator picks sigma by the same rule."""
+    from oracle import awgn_model, fnn_oracle as O
+    Ws, bs = _net()
+    first_row = first_block * ROWS_PER_BLOCK
+    x, labels = awgn_model.generate("133171", B, n_blocks * ROWS_PER_BLOCK, BIN_SIGMAS, SEED, first_row=first_row,
+                                    rows_per_block=ROWS_PER_BLOCK)
+    cls, _, _ = O.decode(x.astype(np.float32), Ws, bs, B)
+    out = np.zeros((N_BINS, 4), np.int64)
+    bins = ((first_row + np.arange(len(cls))) // ROWS_PER_BLOCK) % N_BINS
+    for k in range(N_BINS):
+        m = bins == k
+        if m.any():
+            out[k] = O.error_counters(cls[m], labels[m], B)
+    return out
+
+
+def _binned_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    nd.init_from_env(backend="gloo")
+    first, count = nd.block_shard(N_BLOCKS, rank, world)
+    c = torch.from_numpy(_binned_counters_for(first, count))
+    mine = c.clone()
+    nd.barrier()
+    nd.all_reduce_counters(c)                         # [7, 4] int64: the configs[3] leg's one collective
+    per_rank_blocks = nd.gather_ints(count)
+    np.save(os.path.join(out_dir, f"b{rank}.npy"), np.concatenate([c.numpy().ravel(), mine.numpy().ravel(), per_rank_blocks]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_binned_counter_reduction_equals_single_rank(tmp_path, world):
+    """bench.py's configs[3] leg on CPU: contiguous shards of 101 blocks (not divisible by 2, 4 or 7), per-SNR-bin
+    counters reduced by ONE all-reduce == one rank decoding every block; a rank's own share is a strict part."""
+    mp.spawn(_binned_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    full = _binned_counters_for(0, N_BLOCKS)
+    assert full[:, 3].tolist() == [ROWS_PER_BLOCK * len(range(k, N_BLOCKS, N_BINS)) for k in range(N_BINS)]
+    assert (full[:, 2] == B * full[:, 3]).all() and full[:, 0].sum() > 0
+    shares = np.zeros((N_BINS, 4), np.int64)
+    for r in range(world):
+        got = np.load(tmp_path / f"b{r}.npy")
+        assert got[:28].reshape(N_BINS, 4).tolist() == full.tolist()
+        shares += got[28:56].reshape(N_BINS, 4)
+        assert got[56:].tolist() == [nd.block_shard(N_BLOCKS, q, world)[1] for q in range(world)]
+    assert shares.tolist() == full.tolist()
+
+
 def test_gather_ints_single_process():
     assert nd.gather_ints(7) == [7]
 
