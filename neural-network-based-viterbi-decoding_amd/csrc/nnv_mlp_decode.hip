@@ -232,26 +232,42 @@ constexpr float kTanhSat = 9.011f;
 // from here up distinct pre-activations share an fp32 tanh value over spans wider than 0.25 in z
 constexpr float kFlatBand = 7.9f;
 
+// 16-byte aligned rows of an even, 4-divisible half width: G1 dwordx4 loads per lane (tail rows: clamped, discarded)
 template <int G1, bool VEC_ONLY>
 __device__ __forceinline__ void load_x(const DecodeParams &p, int64_t tile,
                                        int j, int half, float (&xr)[4 * G1]) {
   int64_t row = tile * kRowsPerTile + j;
   row = row < p.n_rows ? row : p.n_rows - 1;  // tail rows: valid memory, discarded
   const float *px = p.x + row * p.n_in + half * p.bp;
-  if (VEC_ONLY || p.xvec) {
 #pragma unroll
-    for (int g = 0; g < G1; ++g) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (4 * g < p.bp) v = *reinterpret_cast<const f32x4 *>(px + 4 * g);
+  for (int g = 0; g < G1; ++g) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (4 * g < p.bp) v = *reinterpret_cast<const f32x4 *>(px + 4 * g);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) xr[4 * g + e] = v[e];
-    }
-  } else {
+    for (int e = 0; e < 4; ++e) xr[4 * g + e] = v[e];
+  }
+}
+
+// Rows that are only dword aligned (half width bp not a multiple of 4: b = 5, 6, 7, 9, 10, 11 -- the reference's own
+// default b = 7 among them): 4 XG dword buffer loads per lane from a per-tile descriptor.  The tile's base and the
+// bytes left behind it are scalars, the lane's byte offset is the same for every tile and the element offsets are
+// immediates: no vector-ALU address arithmetic, no row clamp (rows past the end are out of range and load as 0).
+// Elements s >= the lane's valid count are the NEXT half row's values: they are masked to 0 (their packed weights are 0,
+// but 0 x NaN would carry a neighbour's non-finite value into this row).  Only the last TAIL elements can be invalid
+// (fp32: XN = 4 ceil(bp / 4), TAIL = 4; 16-bit modes: XN = 8 ceil(bp / 8), TAIL = 8).
+template <int XN, int TAIL>
+__device__ __forceinline__ void load_x_dwords(const DecodeParams &p, int64_t tile, int64_t tile_bytes, unsigned lane_off,
+                                              const unsigned (&tail_mask)[TAIL], float (&xr)[XN]) {
+  const int64_t off = tile * tile_bytes;                                             // scalar
+  const int64_t left = p.n_rows * p.n_in * 4 - off;
+  const unsigned nrec = left > 0xffffffffLL ? 0xffffffffu : static_cast<unsigned>(left);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>(reinterpret_cast<const char *>(p.x) + off), 0, nrec, 0x00020000);
 #pragma unroll
-    for (int s = 0; s < 4 * G1; ++s) {
-      const bool ok = (s < p.bp) && (half * p.bp + s < p.n_in);
-      xr[s] = ok ? px[s] : 0.f;
-    }
+  for (int s = 0; s < XN; ++s) {
+    unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off + 4u * s, 0, 0);
+    if (s >= XN - TAIL) v &= tail_mask[s - (XN - TAIL)];
+    xr[s] = __builtin_bit_cast(float, v);
   }
 }
 
@@ -368,11 +384,22 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   const unsigned x_off_full = static_cast<unsigned>(j * p.n_in + half * p.bp) * 4u;
   const int64_t last_rows = p.n_rows - (p.n_tiles - 1) * kRowsPerTile;  // 1..32
   const unsigned x_off_last = static_cast<unsigned>((j < last_rows ? j : static_cast<int>(last_rows) - 1) * p.n_in + half * p.bp) * 4u;
+  // dword path: which of the lane's last four elements are its own (valid = min(bp, n_in - half * bp))
+  constexpr int XTAIL = PREC == kPrecF32 ? 4 : 8;
+  static_assert(XN >= XTAIL, "the masked tail is part of the lane's elements");
+  unsigned x_tail_mask[XTAIL];
+  {
+    const int valid = p.bp < p.n_in - half * p.bp ? p.bp : p.n_in - half * p.bp;
+#pragma unroll
+    for (int e = 0; e < XTAIL; ++e) x_tail_mask[e] = (XN - XTAIL + e) < valid ? 0xffffffffu : 0u;
+  }
   auto fetch_x = [&](int64_t t, float (&dst)[XN]) {
     if constexpr (LEAN && PREC == kPrecF32) {
       load_x_lean<XG>(reinterpret_cast<const char *>(p.x) + t * x_tile_bytes, t == p.n_tiles - 1 ? x_off_last : x_off_full, dst);
+    } else if (LEAN || p.xvec) {
+      load_x<XG, true>(p, t, j, half, dst);
     } else {
-      load_x<XG, LEAN>(p, t, j, half, dst);
+      load_x_dwords<XN, XTAIL>(p, t, x_tile_bytes, x_off_full, x_tail_mask, dst);
     }
   };
   if (tile < p.n_tiles) fetch_x(tile, xr);
