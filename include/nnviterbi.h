@@ -39,6 +39,9 @@ extern "C" {
 
 #define NNV_ABI_VERSION 6 /* 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS; 6: + nnv_wide_set_path / _get_path, nnv_bitwise_set_path / _path_for (no environment switches any more) */
 #define NNV_MAX_LAYERS 4 /* dense layers incl. the output layer */
+#define NNV_MLP_MAX_INPUTS 32     /* nnv_mlp_*: row length n_input = 2 b (block_length <= 16); hidden widths: the first 1-3 of
+                                     the reference's (128, 64, 32); other shapes: NNV_ERR_UNSUPPORTED_SHAPE -> nnv_wide_* */
+#define NNV_MLP_MAX_CLASSES 65536 /* nnv_mlp_*: class layer (2^16); beyond: NNV_ERR_UNSUPPORTED_SHAPE */
 
 typedef enum nnv_status {
   NNV_OK = 0,

@@ -39,6 +39,7 @@ nnv_status shape_from_desc(const nnv_mlp_desc *net, int32_t precision, PackedSha
   s->g1 = precision == nnv::kPrecF32 ? ceil_div(s->bp, 4) : 2 * ceil_div(s->bp, 8);
   for (int i = 0; i < s->nhid; ++i) s->mt[i] = ceil_div(net->dims[i + 1], 32);
   s->n_classes = net->dims[net->depth];
+  if (s->n_classes > NNV_MLP_MAX_CLASSES) return NNV_ERR_UNSUPPORTED_SHAPE;
   s->mt_out = ceil_div(s->n_classes, 32);
   s->kt_out = s->mt[s->nhid - 1];
   // fp32: g1 groups per M-tile; f16x3: (g1/2) k-steps x {hi, lo} = g1 groups as well; f16: hi only = g1/2
@@ -278,7 +279,8 @@ int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision, nnv_mlp_h
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NNV_ERR_NO_DEVICE;
   if (!is_gfx950(prop)) return NNV_ERR_NO_DEVICE;
-  if ((s0.hid_floats + s0.bias_floats) * 4 > kLdsLimitBytes) return NNV_ERR_UNSUPPORTED_SHAPE;
+  // hidden layers and their biases must fit the LDS (the class layer and ITS biases may be streamed: decode_configure)
+  if ((s0.hid_floats + s0.bias_floats - 32LL * s0.mt_out) * 4 > kLdsLimitBytes) return NNV_ERR_UNSUPPORTED_SHAPE;
 
   std::vector<float> packed;
   if (s0.precision != nnv::kPrecF32) {

@@ -335,8 +335,12 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
   constexpr int BOOFF = B3OFF + (NHID >= 3 ? 32 * MTC : 0);
 
   const int out_floats = p.mt_out * KT_OUT * KTF;
-  const int bias_floats = (BOOFF - HIDF) + 32 * p.mt_out;
-  const int lds_out = BOOFF + 32 * p.mt_out;  // output groups (if resident)
+  // class-layer biases in LDS: every tile's (resident variants) or the resident tiles' only (stream variant: the
+  // streamed tiles take theirs from global memory with their weights, so a 2^13..2^16-class layer -- block_length
+  // 13..16, 32-256 KB of biases -- needs no LDS for them)
+  const int bias_tiles = STREAM ? p.out_lds_tiles : p.mt_out;
+  const int bias_floats = (BOOFF - HIDF) + 32 * bias_tiles;
+  const int lds_out = BOOFF + 32 * bias_tiles;  // output groups (if resident)
   // one 32-bit work counter behind the packed network (decode_plan reserves it)
   const int out_lds_floats = p.out_lds_tiles * KT_OUT * KTF;  // resident part of the class layer
   unsigned *tile_ctr = reinterpret_cast<unsigned *>(lds + lds_out + out_lds_floats);
@@ -620,6 +624,23 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(p.wpack + HIDF + static_cast<int64_t>(first) * GPT * kFragGroupFloats), 0, n_groups * 1024, 0x00020000);
         const unsigned lane_off16 = static_cast<unsigned>(lane_opaque) * 16u;
+        // the streamed tiles' biases: [tile][32] floats behind the class weights in the packed network; a lane needs
+        // the 16 of its half (4 x 16 bytes, the same for all 32 lanes of a half: one cache line per tile), requested
+        // one tile ahead into the registers that become the NEXT tile's accumulator
+        const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(p.wpack + HIDF + out_floats + (BOOFF - HIDF) + 32 * static_cast<int64_t>(first)), 0,
+            (p.mt_out - first) * 128, 0x00020000);
+        const unsigned bias_off = static_cast<unsigned>(half) * 16u;
+        auto load_bias = [&](int t, f32x16 &dst) {       // tile `first + t`; past the end: zeros (unused)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, bias_off + 32u * q, t * 128, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[4 * q + e] = bv[e];
+          }
+        };
+        f32x16 next_bias;
+        load_bias(0, next_bias);
         u32x4 a[D][UG];
         auto load_unit = [&](int u, int slot) {          // past the end: the range check returns 0 (unused)
 #pragma unroll
@@ -629,7 +650,8 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
         for (int i = 0; i < D; ++i) load_unit(i, i);
         int u0 = 0;
         for (int mt = first; mt < p.mt_out; ++mt) {
-          f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
+          f32x16 acc = next_bias;
+          load_bias(mt - first + 1, next_bias);
 #pragma unroll
           for (int j = 0; j < UPT; ++j) {
             if constexpr (PREC == kPrecF32) {
@@ -681,8 +703,9 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
       if (__builtin_expect(__builtin_amdgcn_ballot_w64(best >= kFlatBand) != 0, 0)) {
         float tb = -__builtin_inff();
         int ti = 0;
+        const float *g_class_bias = p.wpack + HIDF + out_floats + (BOOFF - HIDF);   // every tile's, in global memory
         for (int mt = 0; mt < p.mt_out; ++mt) {
-          f32x16 acc = init_acc(lds + BOOFF + 32 * mt, half);
+          f32x16 acc = init_acc(STREAM ? g_class_bias + 32 * static_cast<int64_t>(mt) : lds + BOOFF + 32 * mt, half);
           acc = dense_tile<PREC, KT_OUT>(hlast, p.wpack + HIDF + static_cast<int64_t>(mt) * KT_OUT * KTF + lo, acc);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -799,7 +822,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #define NNV_K_true(P, G1, NHID, A, B, C, NT) NNV_K1(P, G1, NHID, A, B, C, NT, true, kVarStream)
 
 // The reference's networks: hidden widths are the first NHID of (128, 64, 32)
-// (src/fnn_viterbi.py:35-37) = M-tiles (4, 2, 1); n_in = 2b <= 24.
+// (src/fnn_viterbi.py:35-37) = M-tiles (4, 2, 1); n_in = 2b <= 32.
 #define NNV_FAMILY(P, G1)                                                          \
   NNV_K(P, G1, 1, 4, 1, 1, 512, false), NNV_K(P, G1, 2, 4, 2, 1, 512, false),      \
   NNV_K(P, G1, 3, 4, 2, 1, 512, false), NNV_K(P, G1, 1, 4, 1, 1, 1024, false),     \
@@ -810,6 +833,7 @@ __global__ __launch_bounds__(NT) void mlp_decode_kernel(const DecodeParams p) {
 #if NNV_TU_PREC == 0
 extern const KernelEntry kKernelsF32[] = {
     NNV_FAMILY(kPrecF32, 1), NNV_FAMILY(kPrecF32, 2), NNV_FAMILY(kPrecF32, 3),
+    NNV_FAMILY(kPrecF32, 4),   // n_in = 26 .. 32: block_length 13 .. 16 (the reference's DecoderConfig goes to 15 in its tests)
 #ifdef NNV_DIAG_ON
     NNV_K(kPrecF32, 2, 3, 4, 2, 1, 256, false),
 #endif

@@ -94,15 +94,16 @@ int decode_kernel_vgprs(const PackedShape &s, int threads, bool lean) {
 int decode_configure(PackedShape *s, int lds_limit) {
   static const bool band_resident = ab_env("NNV_BAND_RESIDENT_512") != nullptr;
   const int64_t whole = (s->hid_floats + s->out_floats + s->bias_floats) * 4 + kLdsTailBytes;
+  const int64_t hidden_bias_floats = s->bias_floats - 32LL * s->mt_out;   // the stream variant keeps only these + its resident tiles' in LDS
   s->streams = 0;
   const int t = pick_threads_impl(*s);
   if (whole + keep_slot_bytes(t) <= lds_limit) return t;
   if (band_resident && t > 512 && whole + keep_slot_bytes(512) <= lds_limit) return 512;
   s->streams = 1;
-  // streamed: hidden layers + biases + winner slots must fit; a network with a very large class layer's biases
-  // (4096 classes: 16 KB) falls back to 512 threads (half the winner slots)
+  // streamed: hidden layers + their biases + winner slots must fit (the class layer's biases follow its tiles: resident
+  // ones in LDS, streamed ones from global memory)
   int ts = pick_threads_impl(*s);
-  const int64_t fixed = (s->hid_floats + s->bias_floats) * 4 + kLdsTailBytes;
+  const int64_t fixed = (s->hid_floats + hidden_bias_floats) * 4 + kLdsTailBytes;
   if (fixed + keep_slot_bytes(ts) > lds_limit && ts > 512 && fixed + keep_slot_bytes(512) <= lds_limit) ts = 512;
   return ts;
 }
@@ -110,13 +111,16 @@ int decode_configure(PackedShape *s, int lds_limit) {
 nnv_status decode_plan(const PackedShape &s, int64_t n_rows, int num_cus,
                        int lds_limit, int threads, LaunchPlan *plan) {
   if (!find_kernel(s, 512, false)) return NNV_ERR_UNSUPPORTED_SHAPE;
-  const int64_t base_floats = s.hid_floats + s.bias_floats;
+  // hidden layers + their biases; a class tile then costs its weights + 128 bytes of bias (resident variants hold
+  // every tile's bias in LDS, the stream variant only its resident tiles')
+  const int64_t hidden_bias_floats = s.bias_floats - 32LL * s.mt_out;
+  const int64_t base_floats = s.hid_floats + hidden_bias_floats + (s.streams ? 0 : 32LL * s.mt_out);
   // Every variant parks the running argmax winner's accumulators in LDS, 64 bytes per thread; the rest of the LDS
   // holds as many class-layer M-tiles as fit (all of them unless this is the stream variant).
   const int64_t scratch = keep_slot_bytes(threads);
   if (base_floats * 4 + kLdsTailBytes + scratch > lds_limit) return NNV_ERR_UNSUPPORTED_SHAPE;
   // as many class-layer M-tiles as fit stay in LDS; every wave streams the remaining ones from L2
-  const int64_t per_tile_bytes = static_cast<int64_t>(class_tile_kb(s.precision, s.kt_out)) * 1024;
+  const int64_t per_tile_bytes = static_cast<int64_t>(class_tile_kb(s.precision, s.kt_out)) * 1024 + (s.streams ? 128 : 0);
   int64_t fit = (lds_limit - kLdsTailBytes - scratch - base_floats * 4) / per_tile_bytes;
   if (fit > s.mt_out) fit = s.mt_out;
   if (s.streams) {  // A/B builds only: cap the resident class tiles of the stream variant

@@ -420,11 +420,13 @@ def test_sliding_window_stream_generated_and_decoded_on_the_device(cuda_device):
 @pytest.mark.parametrize("b,n", [(13, 2999), (15, 1031), (16, 257)])
 def test_decoder_config_block_lengths_beyond_twelve(cuda_device, b, n):
     """The reference's DecoderConfig is exercised up to block_length 15 in its own tests (tests/test_utilities.py:
-    342-348: n_input 30, 32768 classes; src/fnn_viterbi.py:65-73).  From n_in = 26 / 8192 classes on the network goes
-    through the wide path's layer-at-a-time kernels (class layer 32 -> 2^b as one fp32-MFMA GEMM launch, argmax fused
-    into its epilogue).  Through ``fnn_viterbi.predict`` / ``multilayer_perceptron`` AND the torch ops, ragged
-    row counts, against the float64 restatement under the 1e-5 rule; counters exact functions of the classes.
-    2^16 classes is the header's stated limit (NNV_WIDE_MAX_CLASSES); beyond it prepack refuses, loudly."""
+    342-348: n_input 30, 32768 classes; src/fnn_viterbi.py:65-73).  Since round 5 the register-chained kernel K1 takes
+    these shapes itself (n_in <= 32; the 2^b-class layer streamed from L2 per wave WITH its biases, which no longer
+    need LDS), and the wide path's layer-at-a-time kernels take them too (class layer as one fp32-MFMA GEMM launch,
+    argmax fused into its epilogue): BOTH are held to the float64 restatement under the 1e-5 rule here, through
+    ``fnn_viterbi.predict`` / ``multilayer_perceptron``, the torch ops and an explicit WideMLP, ragged row counts;
+    counters exact functions of the classes.  2^16 classes is the header's stated limit for both
+    (NNV_MLP_MAX_CLASSES, NNV_WIDE_MAX_CLASSES); beyond it prepack refuses, loudly."""
     from nnviterbi_amd import decoder
     cfg = fv.DecoderConfig(block_length=b)
     assert (cfg.n_input, cfg.n_classes) == (2 * b, 2 ** b)
@@ -438,6 +440,27 @@ def test_decoder_config_block_lengths_beyond_twelve(cuda_device, b, n):
     c64, _, o64 = O.decode(x, Ws, bs, b, np.float64)
     margin = O.top2_margin(o64)
     decoder.clear_pack_cache()
+    # which kernel: K1's stream variant, a handful of class tiles resident, the rest (and their biases) from L2
+    k1 = decoder.PackedMLP(Ws, bs)
+    info = k1.launch_info(n)
+    assert info["out_layer_in_lds"] == 0 and 0 <= info["class_tiles_in_lds"] < 2 ** b // 32 and info["lds_bytes"] <= 160 * 1024
+    for precision in ("f32", "f16x3"):
+        kp = k1 if precision == "f32" else decoder.PackedMLP(Ws, bs, precision=precision)
+        r = kp.decode(torch.from_numpy(x).cuda(), labels=torch.from_numpy(labels).cuda(), tile_bits=b, want_bits=True)
+        kc = r["cls32"].cpu().numpy()
+        bad = kc != c64
+        assert not bad.any() or margin[bad].max() < TOL, precision
+        assert np.array_equal(r["counters"].cpu().numpy(), O.error_counters(kc, labels, b))
+        assert np.array_equal(r["bits"].cpu().numpy(), O.class_to_bits(kc, b))
+        assert np.abs(kp.forward(torch.from_numpy(x[:101]).cuda()).cpu().numpy() - o64[:101]).max() < TOL
+        kp.close()
+    # the wide path on the same network (what ran these shapes before K1 did)
+    wide = WideMLP(Ws, bs)
+    assert wide.path == "layered"
+    wc = wide.decode(torch.from_numpy(x).cuda())["cls32"].cpu().numpy()
+    bad = wc != c64
+    assert not bad.any() or margin[bad].max() < TOL
+    wide.close()
     # reference-shaped calls
     preds, counters = fv.predict(x, w, bd, labels=labels, tile_bits=b)
     assert preds.dtype == np.int64 and preds.shape == (n,)
@@ -462,10 +485,17 @@ def test_decoder_config_block_lengths_beyond_twelve(cuda_device, b, n):
 
 
 def test_class_layers_beyond_the_stated_limit_are_refused(cuda_device):
+    from nnviterbi_amd.decoder import PackedMLP
     Ws = [np.zeros((34, 32), np.float32), np.zeros((32, 2 ** 17), np.float32)]
     bs = [np.zeros(32, np.float32), np.zeros(2 ** 17, np.float32)]
     with pytest.raises(Exception, match="unsupported"):
         WideMLP(Ws, bs)
+    with pytest.raises(Exception, match="unsupported"):                # K1: 2^17 classes, and 34 inputs
+        PackedMLP([np.zeros((32, 128), np.float32), np.zeros((128, 2 ** 17), np.float32)],
+                  [np.zeros(128, np.float32), np.zeros(2 ** 17, np.float32)])
+    with pytest.raises(Exception, match="unsupported"):
+        PackedMLP([np.zeros((34, 128), np.float32), np.zeros((128, 64), np.float32)],
+                  [np.zeros(128, np.float32), np.zeros(64, np.float32)])
     Ws = [np.zeros((20000, 32), np.float32), np.zeros((32, 4), np.float32)]
     bs = [np.zeros(32, np.float32), np.zeros(4, np.float32)]
     with pytest.raises(Exception, match="unsupported"):
