@@ -36,7 +36,7 @@
 #endif
 
 #define FNN_ORACLE_MAX_LAYERS 8
-#define FNN_ORACLE_MAX_WIDTH 4096
+#define FNN_ORACLE_MAX_WIDTH 65536 /* class layers up to 2^16 (block_length 16) */
 
 /* one dense layer on one row: out[i] = tanhf( (sum_k in[k]*W[k][i]) + b[i] )
  * W is [n_in][n_out] row-major, the reference's right-multiply layout

@@ -75,6 +75,41 @@ def test_fused_decoder_random_shapes(cuda_device, seed, precision):
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("seed", range(6 * SCALE))
+def test_fused_decoder_random_shapes_long_rows(cuda_device, seed, precision):
+    """K1 on row lengths 25..32 (round 5: block_length 13..16; odd lengths included) with class layers from a handful
+    of classes to 20,000 (resident, banded and streamed with their biases), ragged row counts, every output."""
+    rng = np.random.RandomState(7000 + seed)
+    n_hidden = rng.randint(1, 4)
+    n_in = int(rng.randint(25, 33))
+    n_classes = int(rng.choice([3, 64, 257, 1000, 4096, 5000, 20000]))
+    b = max(1, int(np.ceil(np.log2(n_classes))))
+    dims = [n_in] + [128, 64, 32][:n_hidden] + [n_classes]
+    n = int(rng.choice([1, 33, 64, 500, 2049, 40001]))
+    Ws, bs = _net(dims, rng)
+    x = (rng.randn(n, n_in) * 1.3).astype(np.float32)
+    labels = rng.randint(0, n_classes, size=n).astype(np.int32)
+    net = PackedMLP(Ws, bs, precision=precision)
+    xd = torch.from_numpy(x).cuda()
+    r = net.decode(xd, labels=torch.from_numpy(labels).cuda(), tile_bits=b, want_cls64=True, want_bits=True)
+    cls = r["cls32"].cpu().numpy()
+    m = min(n, 600)                                            # the [rows, n_classes] float64 outputs: a sample
+    _check_ff(cls[:m], net.forward(xd[:m]).cpu().numpy(), x[:m], Ws, bs)
+    ref = O.decode_c(x, Ws, bs, b, labels=labels, want_bits=False)
+    diff = np.flatnonzero(cls != ref["cls"])
+    assert len(diff) <= max(2, n // 2000)                       # fp32 vs fp32: near-ties only
+    if len(diff):
+        o64 = O.forward(x[diff], Ws, bs, np.float64)
+        assert O.top2_margin(o64).max() < TOL
+    assert np.array_equal(r["cls64"].cpu().numpy(), cls.astype(np.int64))
+    assert np.array_equal(r["bits"].cpu().numpy(), O.class_to_bits(cls, b))
+    assert np.array_equal(r["counters"].cpu().numpy(), O.error_counters(cls, labels, b))
+    lean = net.decode(xd, labels=torch.from_numpy(labels).cuda(), tile_bits=b)
+    assert np.array_equal(lean["cls32"].cpu().numpy(), cls) and torch.equal(lean["counters"], r["counters"])
+    net.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("seed", range(6 * SCALE))
 def test_fused_decoder_random_shapes_many_rows(cuda_device, seed, precision):
     """K1 over SEVERAL rounds of its persistent workgroups (40 k - 150 k rows: every wave of every workgroup decodes
     more than one row tile, ragged tails), class counts up to 4096 so that the resident, lean and stream variants
