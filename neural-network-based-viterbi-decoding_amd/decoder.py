@@ -618,7 +618,7 @@ def generate_awgn_blocks(code: str, tile_bits: int, n_rows: int, sigma, seed: in
 # the precision and the device -- one prepack for the life of the call site's weights, least-recently-used eviction.
 # ---------------------------------------------------------------------------
 _NET_CACHE: "collections.OrderedDict[tuple, object]" = collections.OrderedDict()
-_NET_CACHE_MAX = 8
+_NET_CACHE_MAX = 4      # a host-decoding PackedMLP also owns its pinned staging ring (256 MB): keep few
 
 
 try:                                   # 128-bit xxh3: ~7 GB/s (a 66 MB bank in 10 ms); blake2b (~0.6 GB/s) if it is absent

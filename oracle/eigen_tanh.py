@@ -28,7 +28,7 @@ TensorFlow 1.0 - 1.13 era.  Later Eigen revisions (vendored by TF 1.14/1.15 and 
 float32") and keep the same coefficients.  Which of the two the reference's user ran depends on the
 TensorFlow 1.x wheel they had (requirements.txt:2 pins a range that does not even contain a working one), so
 the constant is a parameter of the arbiter, not a known fact about the reference: ``tanh(a, clamp=...)``
-takes either, the self-check runs for both, and the class-flip tables of DESIGN.md section 2 quote +-9.  The
+takes either, the self-check runs for both, and the class-flip tables of docs/HISTORY.md section 2 quote +-9.  The
 two differ only for |x| in (7.905, 9], where the late one returns exactly +-1 and the early one values within
 4.5e-7 of it (1 - 2^-24 ... 1 + 2^-22) -- inside the flat
 top that the decode kernel's kFlatBand path (>= 7.9) already treats as ties."""

@@ -10,7 +10,7 @@ numpy (``fnn_oracle.forward``) and C (``fnn_oracle.c``) are two restatements by 
 PyTorch's CPU GEMM/tanh/argmax kernels (MKL/oneDNN sgemm, Sleef tanh, first-max argmax) are the only
 *independent* fp32 implementation of those four ops importable in this image, so every
 implementation (numpy fp32, C fp32, torch-CPU fp32, HIP) is compared against the float64 chain
-under the same near-tie rule, and their pairwise class-flip rates are reported.
+under the same near-tie rule, and their pairwise class-flip rates are reported (docs/HISTORY.md section 2; summary in DESIGN.md section 2).
 This triangulates; it does not pin: TensorFlow's Eigen kernels are a fifth implementation nobody
 here can run.
 

@@ -150,7 +150,7 @@ def _trained_net():
 def _triangulate(x, Ws, bs, b):
     """numpy-f32, C-f32, torch-CPU-f32 and torch-CPU-f64 against the numpy float64 chain: outputs
     within 1e-5, class differences only on rows whose float64 top-2 margin is below 1e-5.
-    Returns the pairwise flip counts (reported in DESIGN.md section 2 via tools/flip_rates.py)."""
+    Returns the pairwise flip counts (reported in docs/HISTORY.md section 2 via tools/flip_rates.py)."""
     import torch
     from oracle import torch_cpu as T
     c64, _, o64 = O.decode(x, Ws, bs, b, np.float64)

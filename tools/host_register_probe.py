@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Probe for DESIGN section 9.5's untried host-path route: instead of staging the caller's pageable rows through
+"""Probe for docs/HISTORY.md section 9.5's untried host-path route: instead of staging the caller's pageable rows through
 pinned slots, page-lock (hipHostRegister) the caller's own pages chunk by chunk on helper threads, one chunk
 ahead of the DMA.  That only pays if pages can be locked AND unlocked faster than the link moves them
 (56.5 GB/s bare pinned H2D).  Measures, on the 5.12 GB configs[2] input: register / unregister GB/s of 64 MB

@@ -1,4 +1,4 @@
-// Microbenchmark behind DESIGN section 9 item 7 (K5): one LSTM(20) time step for 32 sequences as K5 issues it --
+// Microbenchmark behind DESIGN section 5 (K5, priced ceiling; docs/HISTORY.md section 9 item 7): one LSTM(20) time step for 32 sequences as K5 issues it --
 // 3 tiles x 11 dependent v_mfma_f32_32x32x2_f32 + the cell update of 10 units per lane (100 transcendentals) -- against
 // the exact tiling a 16x16x4 layout would allow: 5 tiles x 2 column tiles x 6 dependent v_mfma_f32_16x16x4_f32, the same
 // cell update, + the projection on the vector ALU (5 FMAs + 2 lane exchanges + 2 adds per column tile).
