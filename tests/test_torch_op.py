@@ -498,3 +498,68 @@ def test_reference_shaped_calls_pack_once(cuda_device, capsys, tmp_path):
     assert sum(decoder.PACK_STATS.values()) == base + 4 and changed.shape == first.shape
     capsys.readouterr()
     decoder.clear_pack_cache()
+
+
+@pytest.mark.gpu
+def test_c_abi_is_reentrant_from_host_threads(cuda_device):
+    """include/nnviterbi.h: "stream-ordered, re-entrant, no global mutable state besides a per-(device, kernel)
+    attribute cache".  Four host threads (ctypes releases the GIL inside the calls), each with its OWN handle -- two of
+    them packed inside the thread, concurrently -- its own stream and its own rows, 40 decodes each, K1 resident,
+    K1 streamed, K6 and the bank: every result equals the same handle's single-threaded result."""
+    import threading
+    from nnviterbi_amd.decoder import BitwiseBank, PackedMLP, WideMLP
+    rng = np.random.RandomState(123)
+
+    def net(dims):
+        Ws = [(rng.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+        bs = [(rng.randn(d) * 0.1).astype(np.float32) for d in dims[1:]]
+        return Ws, bs
+
+    specs = [("k1", net([16, 128, 64, 32, 256])), ("k1s", net([20, 128, 64, 1024])), ("k6", net([24, 200, 96, 48, 128])),
+             ("bank", [(rng.randn(64, 30).astype(np.float32) * 0.2, rng.randn(30).astype(np.float32) * 0.1,
+                        rng.randn(30, 2).astype(np.float32), rng.randn(2).astype(np.float32) * 0.1) for _ in range(5)])]
+    n = 30_011
+    xs = {k: torch.from_numpy(rng.randn(n, (v[0][0].shape[0] if k != "bank" else 64)).astype(np.float32)).cuda()
+          for k, v in specs}
+
+    def build(kind, w):
+        if kind == "bank":
+            return BitwiseBank(w)
+        return WideMLP(*w) if kind == "k6" else PackedMLP(*w)
+
+    def run(kind, obj, x):
+        if kind == "bank":
+            return obj.decode(x)["bits"]
+        return obj.decode(x)["cls32"]
+
+    expected = {}
+    for kind, w in specs:                       # single-threaded truth, objects closed again
+        o = build(kind, w)
+        expected[kind] = run(kind, o, xs[kind]).clone()
+        o.close()
+    torch.cuda.synchronize()
+    errors, results = [], {}
+
+    def worker(kind, w, prebuilt):
+        try:
+            torch.cuda.set_device(0)
+            obj = prebuilt if prebuilt is not None else build(kind, w)     # two threads prepack concurrently
+            stream = torch.cuda.Stream()
+            out = []
+            with torch.cuda.stream(stream):
+                for _ in range(40):
+                    out.append(run(kind, obj, xs[kind]))
+            stream.synchronize()
+            results[kind] = all(torch.equal(o, expected[kind]) for o in out)
+            obj.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"{kind}: {type(e).__name__}: {e}")
+
+    prebuilt = {"k1": build("k1", specs[0][1]), "k6": build("k6", specs[2][1])}
+    threads = [threading.Thread(target=worker, args=(k, w, prebuilt.get(k))) for k, w in specs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert results == {k: True for k, _ in specs}, results
