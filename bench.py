@@ -646,7 +646,9 @@ def main():
         print(f"bench.py rank {rank}/{world}: needs an MI355X (no CPU fallback for the decode path)",
               file=sys.stderr, flush=True)
         sys.exit(6)    # not 3: gpurun's own "no box free" verdict must stay distinguishable (tools/gpurun_retry.sh)
-    if backend == "nccl" and world > n_dev:
+    # (test hook: NNV_RCCL_SHARED_GPU_TEST=1 lets several ranks ask RCCL for ONE GPU, which RCCL itself refuses -- the
+    # only way to make RCCL fail for real on a one-GPU box and so to execute the fallback below)
+    if backend == "nccl" and world > n_dev and os.environ.get("NNV_RCCL_SHARED_GPU_TEST") != "1":
         print(f"bench.py rank {rank}/{world}: {world} ranks but {n_dev} GPUs visible (RCCL needs one GPU "
               f"per rank; NNV_DIST_BACKEND=gloo rehearses the N-rank path on fewer)", file=sys.stderr, flush=True)
         sys.exit(6)
@@ -655,15 +657,43 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     _stage("joining the process group")
-    nd.init_from_env(backend=backend if world > 1 else None, device_index=dev_index)
-    _stage("process group up")
-    # proof that the collective spans N ranks: SUM of ones over the data path's own backend
-    ones = torch.ones(1, dtype=torch.int64, device=dev)
-    nd.all_reduce_counters(ones)
-    ranks_seen = int(ones.item())
-    devices = nd.gather_ints(dev_index, device=dev)
-    try:        # before any timing: N ranks, and under RCCL N distinct GPUs, or no value at all
-        nd.validate_group(ranks_seen, devices, world, require_distinct_devices=(backend == "nccl" and world > 1))
+    rccl_error = None
+
+    def first_collective():
+        """proof that the collective spans N ranks: SUM of ones + gather of the device indices over the data path's
+        own backend"""
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        nd.all_reduce_counters(ones)
+        return int(ones.item()), nd.gather_ints(dev_index, device=dev)
+
+    try:
+        nd.init_from_env(backend=backend if world > 1 else None, device_index=dev_index)
+        _stage("process group up")
+        ranks_seen, devices = first_collective()
+    except Exception as e:   # noqa: BLE001
+        # RCCL could not be brought up between these ranks (this pool: IPC handles between processes need
+        # HSA_ENABLE_IPC_MODE_LEGACY=0; a first multi-GPU run is where that shows).  The data path has NO collective:
+        # what RCCL carries is 28 integers after the timed region.  Rather than lose the whole scaling record, reduce
+        # them over gloo -- and SAY SO: `dist_backend` and `rccl_error` in the JSON line, the diagnosis on stderr.
+        # NNV_RCCL_FALLBACK=0 turns this into exit code 7.
+        if world == 1 or backend != "nccl" or os.environ.get("NNV_RCCL_FALLBACK", "1") == "0":
+            print(f"bench.py rank {rank}/{world}: process group ({backend}) failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            sys.exit(7)
+        rccl_error = f"{type(e).__name__}: {str(e).strip().splitlines()[0][:300] if str(e).strip() else ''}"
+        print(f"bench.py rank {rank}/{world}: RCCL process group failed ({rccl_error}); HSA_ENABLE_IPC_MODE_LEGACY="
+              f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')!r}; reducing the counters over gloo instead", file=sys.stderr, flush=True)
+        _stage("RCCL failed, joining a gloo group")
+        nd.reset_group()
+        backend = "gloo"
+        # ranks may arrive here up to one RCCL time-out apart (one rank's init fails at once, another's first
+        # collective only times out): the gloo rendezvous waits that long and a little more
+        os.environ["NNV_DIST_TIMEOUT_S"] = str(2 * nd.group_timeout_s() + 30)
+        nd.init_from_env(backend="gloo", device_index=dev_index)
+        _stage("process group up")
+        ranks_seen, devices = first_collective()
+    try:        # before any timing: N ranks, and N distinct GPUs whenever the node has that many, or no value at all
+        nd.validate_group(ranks_seen, devices, world,
+                          require_distinct_devices=(world > 1 and (backend == "nccl" or (rccl_error is not None and n_dev >= world))))
     except RuntimeError as e:
         print(f"bench.py rank {rank}/{world}: {e}", file=sys.stderr, flush=True)
         sys.exit(5)
@@ -792,7 +822,10 @@ def main():
             "value": world * n_blocks * args.steps / elapsed,
             "unit": "blocks/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "rank_devices": devices,
-            "dist_backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else None),
+            "dist_backend": (("rccl (torch 'nccl')" if backend == "nccl" else
+                              (backend if rccl_error is None else "gloo (FALLBACK: RCCL could not be brought up, see rccl_error)"))
+                             if world > 1 else None),
+            **({"rccl_error": rccl_error} if rccl_error is not None else {}),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "ms_per_step_per_rank": per_rank_ms, "kernel_ms_per_launch_per_rank": per_rank_kernel_ms,

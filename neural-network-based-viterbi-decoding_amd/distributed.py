@@ -85,6 +85,16 @@ def init_from_env(backend: Optional[str] = None, device_index: Optional[int] = N
     return rank, local_rank, world
 
 
+def reset_group() -> None:
+    """Leave whatever process group exists (or half exists after a failed initialisation), so that init_from_env can
+    build another one -- bench.py's fallback from RCCL to gloo for the counters."""
+    try:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:   # noqa: BLE001  (a communicator that never came up may refuse to be torn down; nothing to keep)
+        pass
+
+
 def gather_ints(value: int, device=None, group=None) -> list:
     """[value of rank 0, value of rank 1, ...] on every rank (all_gather of one int64)."""
     if not (dist.is_available() and dist.is_initialized()):

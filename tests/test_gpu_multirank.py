@@ -93,6 +93,32 @@ def test_bench_four_ranks_one_gpu_rehearsal(cuda_device):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(1200)
+def test_rccl_failure_falls_back_to_gloo_and_says_so(cuda_device):
+    """A first multi-GPU run is where RCCL can fail to come up (IPC between processes on this pool).  The data path has
+    no collective -- RCCL carries 28 integers after the timed region -- so bench.py then reduces them over gloo and SAYS
+    SO in the record (`dist_backend`, `rccl_error`) instead of losing the scaling measurement.  Executed for real on
+    one GPU: two ranks ask RCCL for the SAME device (test hook), which RCCL refuses or times out on; the run must still
+    produce one JSON line whose counters equal a single rank's.  NNV_RCCL_FALLBACK=0 makes the same failure exit 7."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs the one-GPU box: with two GPUs RCCL comes up and there is nothing to fall back from")
+    hook = {"NNV_RCCL_SHARED_GPU_TEST": "1", "NNV_DIST_TIMEOUT_S": "40"}
+    two = _bench(2, BLOCKS, hook)
+    one = _bench(1, 2 * BLOCKS)
+    assert "FALLBACK" in two["dist_backend"] and two["rccl_error"], two["dist_backend"]
+    assert two["rank_devices"] == [0, 0]
+    _check_pair(two, one)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(hook, NNV_RCCL_FALLBACK="0", NNV_BENCH_LIVE_TRAFFIC="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--blocks-per-gpu", "1000", "--config3-blocks", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "process group (nccl) failed" in r.stderr
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())      # (RCCL prints its version banner there) no JSON line
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
 def test_bench_two_ranks_rccl(cuda_device):
     if torch.cuda.device_count() < 2:
         pytest.skip("RCCL path needs >= 2 GPUs (the gpurun box has one)")
