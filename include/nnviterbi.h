@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NNV_ABI_VERSION 6 /* 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS; 6: + nnv_wide_set_path / _get_path, nnv_bitwise_set_path / _path_for (no environment switches any more) */
+#define NNV_ABI_VERSION 7 /* 7: + nnv_train_* (the training step as two kernels); prior: 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS; 6: + nnv_wide_set_path / _get_path, nnv_bitwise_set_path / _path_for (no environment switches any more) */
 #define NNV_MAX_LAYERS 4 /* dense layers incl. the output layer */
 #define NNV_MLP_MAX_INPUTS 32     /* nnv_mlp_*: row length n_input = 2 b (block_length <= 16); hidden widths: the first 1-3 of
                                      the reference's (128, 64, 32); other shapes: NNV_ERR_UNSUPPORTED_SHAPE -> nnv_wide_* */
@@ -437,6 +437,57 @@ int32_t nnv_seq2seq_forward_f32(const nnv_seq2seq_handle *h, const float *enc_in
                                 int64_t batch, float *logits_dev, uint8_t *bits_dev,
                                 const uint8_t *info_dev, int32_t n_bits,
                                 uint64_t *counters_dev, void *stream);
+
+/* ------------------------------------------------------------------------
+ * The TRAINING STEP of the feed-forward decoder (ABI 7), SURVEY.md section 8f rank 1:
+ *   cost = reduce_mean(softmax_cross_entropy_with_logits(logits = the TANH'd class layer, labels = y))
+ *          + beta (l2_loss(h1) + l2_loss(h2) + l2_loss(h3))                  src/fnn_viterbi.py:549-559
+ *   tf.train.AdamOptimizer(learning_rate).minimize(cost)                      src/fnn_viterbi.py:561-563
+ *   (TF 1.x: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), epsilon 1e-8 OUTSIDE the bias correction)
+ *   optional tf.nn.dropout after every hidden tanh                src/fnn_viterbi_mixed_snr.py:596-627
+ * for the reference's architecture n_input -> 128 -> 64 -> 32 -> n_classes with n_input <= 32, n_classes <= 256 and a
+ * batch of whole 32-row tiles (other shapes: NNV_ERR_UNSUPPORTED_SHAPE; the Python trainer then runs them through
+ * PyTorch autograd).  One step = one forward/backward kernel (a wave per 32 rows, activations through registers,
+ * gradients through wave-private LDS) + one Adam kernel; no atomics, results independent of the launch.
+ * ------------------------------------------------------------------------ */
+typedef struct nnv_train_desc {
+  int32_t n_input, n_classes, batch_size;
+  int32_t n_hidden[3];          /* must be {128, 64, 32} */
+  float learning_rate;          /* DecoderConfig.learning_rate (1e-4) */
+  float beta_regularization;    /* DecoderConfig.beta_regularization (1e-3) */
+  float keep_prob;              /* 1 = no dropout; < 1: every step call must bring its masks */
+  const float *W_host[4];       /* initial weights [in][out] row-major (initialize_weights, src/fnn_viterbi.py:413-468) */
+  const float *b_host[4];
+} nnv_train_desc;
+
+typedef struct nnv_train_handle nnv_train_handle;
+
+/* Replaces the variables + optimizer slots of run_network's graph (src/fnn_viterbi.py:538-567).  Synchronous. */
+int32_t nnv_train_create(const nnv_train_desc *net, nnv_train_handle **out);
+int32_t nnv_train_free(nnv_train_handle *h);
+
+/*
+ * Replaces n_steps iterations of  sess.run([optimizer, cost], feed_dict={x: batch_x, y: batch_y})
+ * (src/fnn_viterbi.py:574-594) over CONSECUTIVE batches: step t takes rows [t B, (t + 1) B) of x_dev / labels_dev.
+ *  x_dev       [n_steps * B][n_input] fp32
+ *  labels_dev  [n_steps * B] int32: the class of each row (the position of the 1 in the reference's one-hot batch_y)
+ *  masks_dev   nullable {[n_steps * B][128], [n_steps * B][64], [n_steps * B][32]} fp32 0/1 dropout masks
+ *              (required iff keep_prob < 1: the caller draws them, as tf.nn.dropout draws its own)
+ *  costs_dev   nullable [n_steps] fp32 out: the cost of each batch BEFORE its update (what sess.run returns)
+ * Asynchronous on `stream`; steps are stream-ordered.
+ */
+int32_t nnv_train_steps(nnv_train_handle *h, const float *x_dev, const int32_t *labels_dev, int32_t n_steps,
+                        const float *const masks_dev[3], float *costs_dev, void *stream);
+
+/* Parity / debug: cost and the eight gradients of ONE batch at the current weights (tf.gradients of the cost above),
+ * no update.  Synchronous; host outputs in the reference's shapes ([in][out], [out]); any pointer may be NULL. */
+int32_t nnv_train_gradients(nnv_train_handle *h, const float *x_dev, const int32_t *labels_dev,
+                            const float *const masks_dev[3], float *cost_host, float *const gW_host[4],
+                            float *const gb_host[4]);
+
+/* Current weights to the host (the reference's Saver.save, src/fnn_viterbi_mixed_snr.py:782-784) and, if
+ * cost_sum_host is not NULL, the sum of the step costs since the last export (reset by the call).  Synchronous. */
+int32_t nnv_train_export(const nnv_train_handle *h, float *const W_host[4], float *const b_host[4], double *cost_sum_host);
 
 /*
  * Timing helper used by bench.py: launches nnv_mlp_decode_f32 `iters` times

@@ -217,18 +217,161 @@ class FNNTrainer:
                 {k: b.detach().cpu().numpy().copy() for k, b in zip(self.b_keys, self.B)})
 
 
+class NativeFNNTrainer:
+    """The same training step as :class:`FNNTrainer`, as two hand-written HIP kernels per step (C ABI ``nnv_train_*``,
+    csrc/nnv_train.hip): forward + loss + backward in one launch (a wave per 32 rows, activations through registers,
+    weight gradients through wave-private LDS), TF-1 Adam + re-packing of the weights in a second.  ~45 launches of a
+    PyTorch-autograd step become 4; the steps of an epoch are issued by ONE call.
+
+    Eligible: the reference's architecture n_in -> 128 -> 64 -> 32 -> n_classes with n_in <= 32, n_classes <= 256, a
+    batch size that is a multiple of 32, on an MI355X.  Labels are class indices (the position of the 1 in the
+    reference's one-hot rows).  Checked against oracle/train_oracle.py like FNNTrainer (tests/test_trainer.py)."""
+
+    @staticmethod
+    def eligible(weights: Dict, biases: Dict, batch_size: int) -> bool:
+        if not torch.cuda.is_available():
+            return False
+        if [k for k in ("h1", "h2", "h3") if k in weights] != ["h1", "h2", "h3"]:
+            return False
+        shp = [tuple(np.asarray(weights[k]).shape) for k in ("h1", "h2", "h3", "out")]
+        return (shp[0][1], shp[1], shp[2], shp[3][0]) == (128, (128, 64), (64, 32), 32) and shp[0][0] <= 32 \
+            and shp[3][1] <= 256 and batch_size % 32 == 0 and batch_size > 0
+
+    def __init__(self, weights: Dict, biases: Dict, learning_rate: float, beta_regularization: float, batch_size: int,
+                 use_dropout: bool = False, keep_prob: float = 0.5, device=None):
+        import ctypes
+        from . import _cabi
+        self._cabi, self._ctypes = _cabi, ctypes
+        self._lib = _cabi.load_library()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)
+        self.w_keys, self.b_keys = ["h1", "h2", "h3", "out"], ["b1", "b2", "b3", "out"]
+        Ws = [np.ascontiguousarray(np.asarray(weights[k]), dtype=np.float32) for k in self.w_keys]
+        bs = [np.ascontiguousarray(np.asarray(biases[k]), dtype=np.float32).reshape(-1) for k in self.b_keys]
+        self.shapes = [w.shape for w in Ws]
+        self.batch_size = int(batch_size)
+        self.use_dropout, self.keep_prob = bool(use_dropout), float(keep_prob)
+        d = _cabi.TrainDesc()
+        d.n_input, d.n_classes, d.batch_size = Ws[0].shape[0], Ws[3].shape[1], self.batch_size
+        d.n_hidden[0], d.n_hidden[1], d.n_hidden[2] = 128, 64, 32
+        d.learning_rate, d.beta_regularization = float(learning_rate), float(beta_regularization)
+        d.keep_prob = self.keep_prob if self.use_dropout else 1.0
+        for i in range(4):
+            d.W_host[i], d.b_host[i] = Ws[i].ctypes.data, bs[i].ctypes.data
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _cabi.check(self._lib.nnv_train_create(ctypes.byref(d), ctypes.byref(h)), "nnv_train_create")
+        self._handle = h
+
+    def close(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            self._lib.nnv_train_free(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _mask_array(self, masks):
+        if masks is None:
+            return None
+        arr = (self._ctypes.c_void_p * 3)(*[int(m.data_ptr()) for m in masks])
+        return arr
+
+    def _check(self, x, labels, n_steps, masks):
+        n = n_steps * self.batch_size
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (n, self.shapes[0][0])):
+            raise ValueError(f"x must be a contiguous float32 CUDA tensor [{n}, {self.shapes[0][0]}]")
+        if not (labels.is_cuda and labels.dtype == torch.int32 and labels.is_contiguous() and tuple(labels.shape) == (n,)):
+            raise ValueError(f"labels must be a contiguous int32 CUDA tensor [{n}] of class indices")
+        if self.use_dropout and masks is None:
+            raise ValueError("this trainer was built with dropout: pass the three masks")
+        if masks is not None:
+            for m, wdt in zip(masks, (128, 64, 32)):
+                if not (m.is_cuda and m.dtype == torch.float32 and m.is_contiguous() and tuple(m.shape) == (n, wdt)):
+                    raise ValueError(f"masks must be contiguous float32 CUDA tensors [{n}, 128 | 64 | 32]")
+
+    def draw_masks(self, n_rows: int):
+        """Bernoulli(keep_prob) masks for ``n_rows`` rows, as tf.nn.dropout draws floor(keep_prob + U[0, 1))."""
+        return [(torch.rand((n_rows, w), device=self.device) < self.keep_prob).to(torch.float32) for w in (128, 64, 32)]
+
+    def steps(self, x: torch.Tensor, labels: torch.Tensor, n_steps: int, masks=None, want_costs: bool = False):
+        """``n_steps`` consecutive batches (rows [t B, (t+1) B) of ``x`` / ``labels``), stream-ordered, one C call."""
+        self._check(x, labels, n_steps, masks)
+        costs = torch.empty(n_steps, dtype=torch.float32, device=self.device) if want_costs else None
+        marr = self._mask_array(masks)
+        with torch.cuda.device(self.device):
+            st = self._lib.nnv_train_steps(self._handle, x.data_ptr(), labels.data_ptr(), int(n_steps),
+                                           None if marr is None else self._ctypes.cast(marr, self._ctypes.c_void_p),
+                                           None if costs is None else costs.data_ptr(),
+                                           self._ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        self._cabi.check(st, "nnv_train_steps")
+        return costs
+
+    def gradients(self, xb: torch.Tensor, labels: torch.Tensor, masks=None):
+        """(cost, [dW1..dW4, db1..db4]) of one batch at the current weights; no update (parity tests)."""
+        self._check(xb, labels, 1, masks)
+        gW = [np.zeros(s, np.float32) for s in self.shapes]
+        gb = [np.zeros(s[1], np.float32) for s in self.shapes]
+        pw = (self._ctypes.c_void_p * 4)(*[g.ctypes.data for g in gW])
+        pb = (self._ctypes.c_void_p * 4)(*[g.ctypes.data for g in gb])
+        cost = self._ctypes.c_float(0.0)
+        marr = self._mask_array(masks)
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream(self.device).synchronize()
+            st = self._lib.nnv_train_gradients(self._handle, xb.data_ptr(), labels.data_ptr(),
+                                               None if marr is None else self._ctypes.cast(marr, self._ctypes.c_void_p),
+                                               self._ctypes.byref(cost), self._ctypes.cast(pw, self._ctypes.c_void_p),
+                                               self._ctypes.cast(pb, self._ctypes.c_void_p))
+        self._cabi.check(st, "nnv_train_gradients")
+        return float(cost.value), gW + gb
+
+    def export(self, want_cost_sum: bool = False):
+        Ws = [np.zeros(s, np.float32) for s in self.shapes]
+        bs = [np.zeros(s[1], np.float32) for s in self.shapes]
+        pw = (self._ctypes.c_void_p * 4)(*[g.ctypes.data for g in Ws])
+        pb = (self._ctypes.c_void_p * 4)(*[g.ctypes.data for g in bs])
+        csum = self._ctypes.c_double(0.0)
+        with torch.cuda.device(self.device):
+            st = self._lib.nnv_train_export(self._handle, self._ctypes.cast(pw, self._ctypes.c_void_p),
+                                            self._ctypes.cast(pb, self._ctypes.c_void_p),
+                                            self._ctypes.byref(csum) if want_cost_sum else None)
+        self._cabi.check(st, "nnv_train_export")
+        out = (dict(zip(self.w_keys, Ws)), dict(zip(self.b_keys, bs)))
+        return out + (float(csum.value),) if want_cost_sum else out
+
+
 def train_network(config, training_set: np.ndarray, training_labels: np.ndarray,
                   weights: Dict[str, np.ndarray], biases: Dict[str, np.ndarray],
                   use_dropout: bool = False, keep_prob: float = 0.5,
                   verbose: bool = True) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
-    """Returns trained copies of (weights, biases), keyed like the inputs."""
+    """Returns trained copies of (weights, biases), keyed like the inputs.  On an MI355X the reference's architecture
+    trains through the two-kernel step (:class:`NativeFNNTrainer`); other shapes, and ``NNV_TRAINER=autograd``, through
+    PyTorch autograd (:class:`FNNTrainer`), one HIP-graph replay per step."""
+    bs = int(config.batch_size)
+    total_batch = int(config.num_training_samples / bs)
+    if os.environ.get("NNV_TRAINER") != "autograd" and NativeFNNTrainer.eligible(weights, biases, bs) and total_batch > 0:
+        nt = NativeFNNTrainer(weights, biases, config.learning_rate, config.beta_regularization, bs,
+                              use_dropout=use_dropout, keep_prob=keep_prob)
+        dev = nt.device
+        n = total_batch * bs                         # the remainder that does not fill a batch is dropped, as in the reference
+        x_all = torch.as_tensor(np.asarray(training_set)[:n], dtype=torch.float32, device=dev).contiguous()
+        y = np.asarray(training_labels)[:n]
+        lab = torch.as_tensor(np.argmax(y, axis=1) if y.ndim == 2 else y, device=dev).to(torch.int32).contiguous()
+        for epoch in range(int(config.training_epochs)):
+            nt.steps(x_all, lab, total_batch, masks=nt.draw_masks(n) if use_dropout else None)
+            if verbose and epoch % int(getattr(config, "display_step", 1)) == 0:
+                cost_sum = nt.export(want_cost_sum=True)[2]
+                print(f"Epoch: {epoch + 1:04d} | cost = {cost_sum / total_batch:.9f}")
+        out = nt.export()
+        nt.close()
+        return out
     tr = FNNTrainer(weights, biases, config.learning_rate, config.beta_regularization,
                     use_dropout=use_dropout, keep_prob=keep_prob)
     dev = tr.device
     x_all = torch.as_tensor(np.asarray(training_set), dtype=torch.float32, device=dev)
     y_all = torch.as_tensor(np.asarray(training_labels), dtype=torch.float32, device=dev)
-    bs = int(config.batch_size)
-    total_batch = int(config.num_training_samples / bs)
     step = lambda xb, yb: tr.step(xb, yb)
     run = GraphedStep(step, tr.parameters(), tr.opt, [x_all[:bs], y_all[:bs]], verbose) if total_batch > 0 else step
 

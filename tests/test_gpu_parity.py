@@ -913,6 +913,7 @@ def test_graph_captured_training_step_equals_eager(cuda_device, monkeypatch):
     """training.GraphedStep: same kernels in the same order as eager mode -> the same weights; with
     dropout the captured step still draws a fresh mask on every replay."""
     from nnviterbi_amd import training
+    monkeypatch.setenv("NNV_TRAINER", "autograd")      # this test is about the PyTorch path (the two-kernel step: test_trainer.py)
     cfg = fv.DecoderConfig(block_length=6, samples_per_class_train=10, samples_per_class_test=1,
                            training_epochs=3, batch_size=64)
     np.random.seed(11)

@@ -19,7 +19,7 @@ TOL = 1e-6
 
 
 def _problem(b=6, batch=64, seed=3, nonzero_bias=True):
-    cfg = fv.DecoderConfig(block_length=b, samples_per_class_train=4, samples_per_class_test=1,
+    cfg = fv.DecoderConfig(block_length=b, samples_per_class_train=max(4, -(-3 * batch // 2 ** b)), samples_per_class_test=1,
                            learning_rate=1e-4, beta_regularization=0.001, batch_size=batch)
     rng = np.random.RandomState(seed)
     w, bdict = fv.initialize_weights(cfg, rng=rng)
@@ -153,3 +153,83 @@ def test_tfadam_leaves_variables_without_a_gradient_alone():
     (a * 3.0).sum().backward()
     opt.step()
     assert float(b.detach()) == 2.0 and abs(float(a.detach()) - 0.9) < 1e-6
+
+
+# ------------------------------------------------------------------ K7: the step as two hand-written kernels
+def _native_compare(b, batch, use_masks, n_steps=3):
+    cfg, w, bd, x, y, masks = _problem(b=b, batch=batch, seed=10 + b)
+    dev = torch.device("cuda", 0)
+    assert training.NativeFNNTrainer.eligible(w, bd, batch)
+    ref = TO.Trainer(w, bd, cfg.learning_rate, cfg.beta_regularization, keep_prob=0.5)
+    nt = training.NativeFNNTrainer(w, bd, cfg.learning_rate, cfg.beta_regularization, batch, use_dropout=use_masks, keep_prob=0.5)
+    lab = np.argmax(y, axis=1).astype(np.int32)
+    xd = torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
+    ld = torch.as_tensor(lab, device=dev).contiguous()
+    to_dev = lambda ms: [torch.as_tensor(np.concatenate(col), dtype=torch.float32, device=dev).contiguous() for col in zip(*ms)]
+    # cost and the eight gradients of the first batch, before any update
+    m0 = to_dev(masks[:1]) if use_masks else None
+    cost, grads = nt.gradients(xd[:batch], ld[:batch], m0)
+    rcost, dW, db = ref.gradients(x[:batch], y[:batch], masks[0] if use_masks else None)
+    assert abs(cost - rcost) < 2e-6, (cost, rcost)
+    for gname, g, r in zip(["dW1", "dW2", "dW3", "dW4", "db1", "db2", "db3", "db4"], grads, dW + db):
+        assert g.shape == r.shape and np.abs(g.astype(np.float64) - r).max() < TOL, gname
+    # n_steps consecutive batches in ONE call, per-step costs out
+    costs = nt.steps(xd[:n_steps * batch], ld[:n_steps * batch], n_steps, masks=to_dev(masks[:n_steps]) if use_masks else None,
+                     want_costs=True)
+    rc = [ref.step(x[i * batch:(i + 1) * batch], y[i * batch:(i + 1) * batch], masks[i] if use_masks else None) for i in range(n_steps)]
+    assert np.abs(costs.cpu().numpy().astype(np.float64) - np.array(rc)).max() < 2e-6
+    got_w, got_b, cost_sum = nt.export(want_cost_sum=True)
+    assert abs(cost_sum - sum(rc)) < 1e-5
+    for k, r in zip(ref.w_keys, ref.Ws):
+        assert np.abs(got_w[k].astype(np.float64) - r).max() < TOL, k
+        assert np.abs(got_w[k] - w[k]).max() > 1e-4 / 2
+    for k, r in zip(ref.b_keys, ref.bs):
+        assert np.abs(got_b[k].astype(np.float64) - r).max() < TOL, k
+    nt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_masks", [False, True])
+@pytest.mark.parametrize("b,batch", [(6, 64), (7, 256), (8, 256), (6, 32)])
+def test_native_training_step_matches_the_restatement(cuda_device, b, batch, use_masks):
+    """csrc/nnv_train.hip against oracle/train_oracle.py: cost, all eight gradients, three Adam steps (one C call),
+    per-step costs and their running sum, with and without fixed dropout masks; class counts 32..256 (1..8 class tiles),
+    row lengths 10..16, batches of 1..8 workgroups."""
+    _native_compare(b, batch, use_masks)
+
+
+@pytest.mark.gpu
+def test_native_trainer_refuses_what_it_does_not_take(cuda_device):
+    cfg = fv.DecoderConfig(block_length=9)
+    w, bd = fv.initialize_weights(cfg, rng=np.random.RandomState(0))
+    assert not training.NativeFNNTrainer.eligible(w, bd, 256)                 # 512 classes
+    w6, b6 = fv.initialize_weights(fv.DecoderConfig(block_length=6), rng=np.random.RandomState(0))
+    assert not training.NativeFNNTrainer.eligible(w6, b6, 100)                # batch not a multiple of 32
+    with pytest.raises(Exception, match="unsupported"):
+        training.NativeFNNTrainer(w, bd, 1e-4, 1e-3, 256)
+    nt = training.NativeFNNTrainer(w6, b6, 1e-4, 1e-3, 64, use_dropout=True)
+    x = torch.zeros((64, 12), device="cuda")
+    with pytest.raises(ValueError, match="masks"):
+        nt.steps(x, torch.zeros(64, dtype=torch.int32, device="cuda"), 1)
+    nt.close()
+
+
+@pytest.mark.gpu
+def test_train_network_native_and_autograd_agree(cuda_device, monkeypatch, capsys):
+    """training.train_network picks the two-kernel step for the reference's architecture; NNV_TRAINER=autograd keeps the
+    PyTorch path.  Same recipe, same batches: after 3 epochs the weights agree to 2e-5 and the printed costs to 1e-5."""
+    cfg = fv.DecoderConfig(block_length=6, samples_per_class_train=16, samples_per_class_test=1, training_epochs=3, batch_size=64)
+    np.random.seed(5)
+    tr, trl, _, _, _ = fv.train_test_dataset(cfg)
+    w0, b0 = fv.initialize_weights(cfg, rng=np.random.RandomState(9))
+    nw, nb = training.train_network(cfg, tr, trl, w0, b0, verbose=True)
+    native_out = capsys.readouterr().out
+    monkeypatch.setenv("NNV_TRAINER", "autograd")
+    aw, ab = training.train_network(cfg, tr, trl, w0, b0, verbose=True)
+    auto_out = capsys.readouterr().out
+    for k in nw:
+        assert np.abs(nw[k] - aw[k]).max() < 2e-5 and np.abs(nw[k] - w0[k]).max() > 1e-3
+    for k in nb:
+        assert np.abs(nb[k] - ab[k]).max() < 2e-5
+    costs = lambda s: [float(l.split("=")[1]) for l in s.splitlines() if l.startswith("Epoch:")]
+    assert len(costs(native_out)) == 3 and np.abs(np.array(costs(native_out)) - np.array(costs(auto_out))).max() < 1e-5
