@@ -67,6 +67,9 @@ template <int N>
 __device__ __forceinline__ void load_frags(const float *frag, int lane, f32x4 (&a)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) a[i] = *reinterpret_cast<const f32x4 *>(frag + (i * 64 + lane) * 4);
+  // keep the requests HERE: left alone, the scheduler sinks every load to just above its four MFMAs (to save
+  // registers), which is exactly the exposed round trip per group this function exists to avoid
+  __builtin_amdgcn_sched_barrier(0);
 }
 // acc += W-tile (its KT * 4 fragment groups at a[0 ..)) * in[0 .. KT)
 template <int KT>
@@ -136,32 +139,36 @@ __device__ __forceinline__ void bias_grad(const float *zs, int tiles, int lane, 
   }
 }
 
-// hidden activation: tanh, optional dropout (x * mask / keep_prob, src/fnn_viterbi_mixed_snr.py:613-624)
-__device__ __forceinline__ void activate(f32x16 &acc, const float *mask, int width, int mt, int64_t grow, int half, float inv_keep) {
+// hidden activation: tanh, optional dropout (x * mask / keep_prob, src/fnn_viterbi_mixed_snr.py:613-624).  DROP is a
+// template parameter: a run-time test per element put 221 branches and their address arithmetic into the no-dropout
+// kernel, and with fp32 MFMAs every vector instruction is paid for.
+template <bool DROP>
+__device__ __forceinline__ void activate(f32x16 &acc, const float *mask_row, int mt, int half, float inv_keep) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     float h = fast_tanh(acc[r]);
-    if (mask) h *= mask[grow * width + 32 * mt + neuron_of(r, half)] * inv_keep;
+    if constexpr (DROP) h *= mask_row[32 * mt + neuron_of(r, half)] * inv_keep;
     acc[r] = h;
   }
 }
 
 // dz = dh * (dropout scale) * (1 - a^2), a = the tanh BEFORE dropout (= a_dropped * keep where the mask is 1; where it is 0
 // the gradient is 0 whatever a was)
-__device__ __forceinline__ void through_tanh(f32x16 &dh, const f32x16 &hd, const float *mask, int width, int mt, int64_t grow,
-                                             int half, float inv_keep, float keep) {
+template <bool DROP>
+__device__ __forceinline__ void through_tanh(f32x16 &dh, const f32x16 &hd, const float *mask_row, int mt, int half,
+                                             float inv_keep, float keep) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     float d = dh[r], a = hd[r];
-    if (mask) {
-      d *= mask[grow * width + 32 * mt + neuron_of(r, half)] * inv_keep;
+    if constexpr (DROP) {
+      d *= mask_row[32 * mt + neuron_of(r, half)] * inv_keep;
       a *= keep;
     }
     dh[r] = d * (1.0f - a * a);
   }
 }
 
-template <int MTC>
+template <int MTC, bool DROP>
 __global__ __launch_bounds__(64) void train_fwd_bwd_kernel(const TrainParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *const hs0 = lds;                       // x        [32][36]
@@ -177,6 +184,10 @@ __global__ __launch_bounds__(64) void train_fwd_bwd_kernel(const TrainParams p) 
   constexpr int oW1 = 0, oW2 = oW1 + 32 * kH1, oW3 = oW2 + kH1 * kH2, oW4 = oW3 + kH2 * kH3, ob1 = oW4 + kH3 * CP,
                 ob2 = ob1 + kH1, ob3 = ob2 + kH2, ob4 = ob3 + kH3;
   const float keep = 1.0f / p.inv_keep;
+  // this lane's row of the three dropout masks (DROP only)
+  const float *const mk1 = DROP ? p.mask[0] + grow * kH1 : nullptr;
+  const float *const mk2 = DROP ? p.mask[1] + grow * kH2 : nullptr;
+  const float *const mk3 = DROP ? p.mask[2] + grow * kH3 : nullptr;
 
   // ---------------- forward ----------------
   f32x16 xt[kT0];
@@ -189,32 +200,34 @@ __global__ __launch_bounds__(64) void train_fwd_bwd_kernel(const TrainParams p) 
   f32x16 h1[kT1], h2[kT2], h3[kT3];
   f32x4 f1[kT1 * kT0 * 4];
   load_frags(p.wf[0], lane, f1);
+  f32x4 f2[kT2 * kT1 * 4];               // the NEXT layer's fragments are requested before this layer's MFMAs
+  load_frags(p.wf[1], lane, f2);
 #pragma unroll
   for (int mt = 0; mt < kT1; ++mt) {
     h1[mt] = chain<kT0>(xt, f1 + mt * kT0 * 4, bias_tile(p.bias[0], mt, half));
-    activate(h1[mt], p.mask[0], kH1, mt, grow, half, p.inv_keep);
+    activate<DROP>(h1[mt], mk1, mt, half, p.inv_keep);
     put_tile(hs1, mt, h1[mt], row, half);
-  }
-  f32x4 f2[kT2 * kT1 * 4];
-  load_frags(p.wf[1], lane, f2);
-#pragma unroll
-  for (int mt = 0; mt < kT2; ++mt) {
-    h2[mt] = chain<kT1>(h1, f2 + mt * kT1 * 4, bias_tile(p.bias[1], mt, half));
-    activate(h2[mt], p.mask[1], kH2, mt, grow, half, p.inv_keep);
-    put_tile(hs2, mt, h2[mt], row, half);
   }
   f32x4 f3[kT3 * kT2 * 4];
   load_frags(p.wf[2], lane, f3);
+  f32x4 f4[MTC * kT3 * 4];
+  load_frags(p.wf[3], lane, f4);
+#pragma unroll
+  for (int mt = 0; mt < kT2; ++mt) {
+    h2[mt] = chain<kT1>(h1, f2 + mt * kT1 * 4, bias_tile(p.bias[1], mt, half));
+    activate<DROP>(h2[mt], mk2, mt, half, p.inv_keep);
+    put_tile(hs2, mt, h2[mt], row, half);
+  }
   h3[0] = chain<kT2>(h2, f3, bias_tile(p.bias[2], 0, half));
-  activate(h3[0], p.mask[2], kH3, 0, grow, half, p.inv_keep);
+  activate<DROP>(h3[0], mk3, 0, half, p.inv_keep);
   put_tile(hs3, 0, h3[0], row, half);
 
   // class layer: p = tanh(z4); softmax cross-entropy ON p (the reference passes the tanh'd tensor as logits)
   f32x16 pz[MTC];
   const int label = p.labels[grow];
   float sum_e = 0.f, p_label = 0.f;
-  f32x4 f4[MTC * kT3 * 4];
-  load_frags(p.wf[3], lane, f4);
+  f32x4 b4[kT3 * MTC * 4];               // backward fragments of the class layer: requested before its forward MFMAs
+  load_frags(p.wb[3], lane, b4);
 #pragma unroll
   for (int mt = 0; mt < MTC; ++mt) {
     pz[mt] = chain<kT3>(h3, f4 + mt * kT3 * 4, bias_tile(p.bias[3], mt, half));
@@ -251,6 +264,10 @@ __global__ __launch_bounds__(64) void train_fwd_bwd_kernel(const TrainParams p) 
 
   // ---------------- backward ----------------
   // layer 4: dW4 = h3^T dz4, db4; dh3 = W4 dz4
+  f32x4 b3[kT2 * kT3 * 4];
+  load_frags(p.wb[2], lane, b3);
+  f32x4 b2[kT1 * kT2 * 4];
+  load_frags(p.wb[1], lane, b2);
   for (int jt = 0; jt < MTC; ++jt) grad_tile(hs3, zs, 0, jt, lane, g + oW4, CP);
   bias_grad(zs, MTC, lane, g + ob4);
   f32x16 d3[kT3];
@@ -258,25 +275,21 @@ __global__ __launch_bounds__(64) void train_fwd_bwd_kernel(const TrainParams p) 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    f32x4 b4[kT3 * MTC * 4];
-    load_frags(p.wb[3], lane, b4);
     d3[0] = chain<MTC>(pz, b4, acc);
-    through_tanh(d3[0], get_tile(hs3, 0, row, half), p.mask[2], kH3, 0, grow, half, p.inv_keep, keep);
+    through_tanh<DROP>(d3[0], get_tile(hs3, 0, row, half), mk3, 0, half, p.inv_keep, keep);
     put_tile(zs, 0, d3[0], row, half);
   }
   // layer 3: dW3 = h2^T dz3 (2 x 1 tiles), db3; dh2 = W3 dz3
   for (int it = 0; it < kT2; ++it) grad_tile(hs2, zs, it, 0, lane, g + oW3, kH3);
   bias_grad(zs, kT3, lane, g + ob3);
   f32x16 d2[kT2];
-  f32x4 b3[kT2 * kT3 * 4];
-  load_frags(p.wb[2], lane, b3);
 #pragma unroll
   for (int kt = 0; kt < kT2; ++kt) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     d2[kt] = chain<kT3>(d3, b3 + kt * kT3 * 4, acc);
-    through_tanh(d2[kt], get_tile(hs2, kt, row, half), p.mask[1], kH2, kt, grow, half, p.inv_keep, keep);
+    through_tanh<DROP>(d2[kt], get_tile(hs2, kt, row, half), mk2, kt, half, p.inv_keep, keep);
   }
 #pragma unroll
   for (int kt = 0; kt < kT2; ++kt) put_tile(zs, kt, d2[kt], row, half);
@@ -285,15 +298,13 @@ __global__ __launch_bounds__(64) void train_fwd_bwd_kernel(const TrainParams p) 
     for (int jt = 0; jt < kT2; ++jt) grad_tile(hs1, zs, it, jt, lane, g + oW2, kH2);
   bias_grad(zs, kT2, lane, g + ob2);
   f32x16 d1[kT1];
-  f32x4 b2[kT1 * kT2 * 4];
-  load_frags(p.wb[1], lane, b2);
 #pragma unroll
   for (int kt = 0; kt < kT1; ++kt) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     d1[kt] = chain<kT2>(d2, b2 + kt * kT2 * 4, acc);
-    through_tanh(d1[kt], get_tile(hs1, kt, row, half), p.mask[0], kH1, kt, grow, half, p.inv_keep, keep);
+    through_tanh<DROP>(d1[kt], get_tile(hs1, kt, row, half), mk1, kt, half, p.inv_keep, keep);
   }
 #pragma unroll
   for (int kt = 0; kt < kT1; ++kt) put_tile(zs, kt, d1[kt], row, half);
@@ -380,15 +391,24 @@ __global__ __launch_bounds__(256) void train_adam_kernel(const AdamParams p) {
     ticket = atomicAdd(p.done, 1u);
   }
   __syncthreads();
-  if (ticket == gridDim.x - 1 && threadIdx.x == 0) {
+  if (ticket == gridDim.x - 1) {   // block-uniform: the last block sums the shares in parallel (fixed order per lane)
     __threadfence();
-    float r = 0.f, c = 0.f;
-    for (unsigned b = 0; b < gridDim.x; ++b) r += __builtin_nontemporal_load(p.reg_part + b);
-    for (int w = 0; w < p.n_wg; ++w) c += p.cost_part[w];
-    c += p.beta_reg * r;
-    if (p.cost_out) *p.cost_out = c;
-    if (p.cost_sum) *p.cost_sum += c;
-    *p.done = 0u;
+    float r = 0.f;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) r += __builtin_nontemporal_load(p.reg_part + b);
+    float c = 0.f;
+    for (int w = threadIdx.x; w < p.n_wg; w += 256) c += p.cost_part[w];
+    float t = c + p.beta_reg * r;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    __syncthreads();                       // wave_reg is reused
+    if ((threadIdx.x & 63) == 0) wave_reg[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float total = (wave_reg[0] + wave_reg[1]) + (wave_reg[2] + wave_reg[3]);
+      if (p.cost_out) *p.cost_out = total;
+      if (p.cost_sum) *p.cost_sum += total;
+      *p.done = 0u;
+    }
   }
 }
 
@@ -415,16 +435,21 @@ using nnv::kH1;
 using nnv::kH2;
 using nnv::kH3;
 
-template <int MTC>
-void launch_fwd_bwd(const nnv::TrainParams &p, int n_wg, hipStream_t s) {
+template <int MTC, bool DROP>
+void launch_one(const nnv::TrainParams &p, int n_wg, hipStream_t s) {
   const int lds = (32 + kH1 + kH2 + kH3 + (MTC * 32 > kH1 ? MTC * 32 : kH1)) * nnv::kS * 4;
   static bool optin = false;   // > 64 KB of dynamic LDS must be opted into once per process and instantiation
   if (!optin) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nnv::train_fwd_bwd_kernel<MTC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nnv::train_fwd_bwd_kernel<MTC, DROP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     optin = true;
   }
-  hipLaunchKernelGGL(nnv::train_fwd_bwd_kernel<MTC>, dim3(n_wg), dim3(64), lds, s, p);
+  hipLaunchKernelGGL((nnv::train_fwd_bwd_kernel<MTC, DROP>), dim3(n_wg), dim3(64), lds, s, p);
+}
+template <int MTC>
+void launch_fwd_bwd(const nnv::TrainParams &p, int n_wg, hipStream_t s) {
+  if (p.mask[0]) launch_one<MTC, true>(p, n_wg, s);
+  else launch_one<MTC, false>(p, n_wg, s);
 }
 
 nnv_status run_fwd_bwd(const nnv_train_handle *h, const float *x, const int32_t *labels, const float *const masks[3],
