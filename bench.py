@@ -369,6 +369,42 @@ def next_row_paths(dev, steps: int):
     one.close()
     out["bitwise_one_position"] = {"workload": f"1 bit position x {nb} rows, {cfgb.n_input}-{cfgb.n_hidden_1}-2 ReLU, exact fp32, "
                                                f"untrained weights ({4 * cfgb.n_input + 1} algorithmic bytes per row)", **res1}
+    del xb
+    # the reference's training step (src/fnn_viterbi.py:549-594: softmax-CE on the tanh outputs
+    # + beta l2(h1..h3), TF-1 Adam, batch 256) on BASELINE configs[2]'s network -- K7 (csrc/nnv_train.hip: forward + loss +
+    # backward in one launch, Adam + repack in a second) beside PyTorch autograd replayed from a HIP graph.
+    from nnviterbi_amd import training
+    cfgt = fv.DecoderConfig(block_length=TILE_BITS)
+    wt, bt = fv.initialize_weights(cfgt, rng=np.random.RandomState(0))
+    bs_t, steps_t = int(cfgt.batch_size), 250
+    xt = torch.randn((steps_t * bs_t, cfgt.n_input), device=dev, generator=g)
+    lt = torch.randint(0, cfgt.n_classes, (steps_t * bs_t,), device=dev, dtype=torch.int32, generator=g)
+    nt = training.NativeFNNTrainer(wt, bt, cfgt.learning_rate, cfgt.beta_regularization, bs_t, device=dev)
+    nt.steps(xt, lt, steps_t)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    costs = nt.steps(xt, lt, steps_t, want_costs=True)
+    torch.cuda.synchronize(dev)
+    us_native = (time.perf_counter() - t0) / steps_t * 1e6
+    nt.close()
+    yt = torch.nn.functional.one_hot(lt.long(), cfgt.n_classes).to(torch.float32)
+    at = training.FNNTrainer(wt, bt, cfgt.learning_rate, cfgt.beta_regularization, device=dev)
+    run = training.GraphedStep(lambda xb_, yb_: at.step(xb_, yb_), at.parameters(), at.opt, [xt[:bs_t], yt[:bs_t]])
+    for i in range(10):
+        run(xt[i * bs_t:(i + 1) * bs_t], yt[i * bs_t:(i + 1) * bs_t])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(100):
+        run(xt[i * bs_t:(i + 1) * bs_t], yt[i * bs_t:(i + 1) * bs_t])
+    torch.cuda.synchronize(dev)
+    us_auto = (time.perf_counter() - t0) / 100 * 1e6
+    macs = sum(int(np.prod(v.shape)) for v in wt.values())
+    out["training_step"] = {"workload": f"the reference's training step, batch {bs_t}, {'-'.join(str(d) for d in fv.layer_dims(cfgt))}, "
+                                        f"{steps_t} consecutive steps in one call, random rows",
+                            "two_kernel_step_K7": {"us_per_step": us_native, "steps_per_s": 1e6 / us_native,
+                                                   "algorithmic_tflops": 6 * macs * bs_t / (us_native * 1e-6) / 1e12,
+                                                   "cost_first_last": [float(costs[0].item()), float(costs[-1].item())]},
+                            "autograd_from_hip_graph": {"us_per_step": us_auto, "graph_captured": bool(run.captured)}}
     return out
 
 
