@@ -43,5 +43,16 @@ for b in (7, 8):
     torch.cuda.synchronize()
     res["autograd_hip_graph_us_per_step"] = (time.perf_counter() - t0) / steps * 1e6
     res["graph_captured"] = run.captured
+    # the same step on the host's cores (PyTorch CPU kernels; the reference's TensorFlow-CPU path is not installable offline)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))     # the box's CPU share, not its 128 hardware threads
+    ct = training.FNNTrainer(w, bd, cfg.learning_rate, cfg.beta_regularization, device="cpu")
+    xc, yc = x[:50 * bs].cpu(), y[:50 * bs].cpu()
+    for i in range(5):
+        ct.step(xc[i * bs:(i + 1) * bs], yc[i * bs:(i + 1) * bs])
+    t0 = time.perf_counter()
+    for i in range(50):
+        ct.step(xc[i * bs:(i + 1) * bs], yc[i * bs:(i + 1) * bs])
+    res["torch_cpu_us_per_step"] = (time.perf_counter() - t0) / 50 * 1e6
+    res["torch_cpu_threads"] = torch.get_num_threads()
     out[f"b{b}"] = res
 print(json.dumps(out))
