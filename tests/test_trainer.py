@@ -233,3 +233,38 @@ def test_train_network_native_and_autograd_agree(cuda_device, monkeypatch, capsy
         assert np.abs(nb[k] - ab[k]).max() < 2e-5
     costs = lambda s: [float(l.split("=")[1]) for l in s.splitlines() if l.startswith("Epoch:")]
     assert len(costs(native_out)) == 3 and np.abs(np.array(costs(native_out)) - np.array(costs(auto_out))).max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_in,n_classes,batch", [(11, 50, 96), (32, 256, 32), (7, 2, 64), (20, 200, 160)])
+def test_native_training_step_on_ragged_shapes(cuda_device, n_in, n_classes, batch):
+    """K7 outside the 2^b family: odd row lengths (zero-padded to one 32-wide k-tile), class counts that are not multiples
+    of 32 (the padding classes must take no part in the softmax and get no gradient), batches of 1..5 workgroups --
+    cost, gradients and three steps against the float64 restatement."""
+    rng = np.random.RandomState(n_in * 1000 + n_classes)
+    dims = [n_in, 128, 64, 32, n_classes]
+    w = {k: (rng.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i, k in enumerate(("h1", "h2", "h3", "out"))}
+    bd = {k: (rng.randn(dims[i + 1]) * 0.1).astype(np.float32) for i, k in enumerate(("b1", "b2", "b3", "out"))}
+    x = rng.randn(3 * batch, n_in).astype(np.float32)
+    lab = rng.randint(0, n_classes, 3 * batch).astype(np.int32)
+    y = np.eye(n_classes, dtype=np.float32)[lab]
+    ref = TO.Trainer(w, bd, 1e-4, 1e-3)
+    nt = training.NativeFNNTrainer(w, bd, 1e-4, 1e-3, batch)
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda()
+    cost, grads = nt.gradients(xd[:batch], ld[:batch])
+    rcost, dW, db = ref.gradients(x[:batch], y[:batch])
+    assert abs(cost - rcost) < 2e-6
+    for g, r in zip(grads, dW + db):
+        assert g.shape == r.shape and np.abs(g.astype(np.float64) - r).max() < TOL
+    costs = nt.steps(xd, ld, 3, want_costs=True).cpu().numpy()
+    rc = [ref.step(x[i * batch:(i + 1) * batch], y[i * batch:(i + 1) * batch]) for i in range(3)]
+    assert np.abs(costs - np.array(rc)).max() < 2e-6
+    got_w, got_b = nt.export()
+    # weights after three Adam steps: Adam divides by sqrt(v) + 1e-8, so where a gradient entry is itself ~1e-8 (random
+    # dense data makes some) fp32 rounding of the gradient moves the update by a few percent of lr = 1e-4: 5e-6 here, where
+    # the gradients themselves are held to 1e-6 above
+    for k, r in zip(ref.w_keys, ref.Ws):
+        assert np.abs(got_w[k].astype(np.float64) - r).max() < 5e-6
+    for k, r in zip(ref.b_keys, ref.bs):
+        assert np.abs(got_b[k].astype(np.float64) - r).max() < 5e-6
+    nt.close()
