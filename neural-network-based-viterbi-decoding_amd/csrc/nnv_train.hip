@@ -6,14 +6,14 @@
 //
 // for the reference's architecture n_in -> 128 -> 64 -> 32 -> n_classes (src/fnn_viterbi.py:35-37) with n_in <= 32 and
 // n_classes <= 256 (block_length <= 8: the reference default 7 and BASELINE's 8).  A PyTorch-autograd step of this
-// network is ~45 tiny kernels, launch-bound at ~0.36 ms even inside a HIP graph; here a step is
+// network is ~45 tiny kernels, launch-bound at ~0.29 ms even inside a HIP graph; here a step is two launches, 37 us:
 //
-//   train_fwd_bwd_kernel  one wave per 32 batch rows (a workgroup of 64 threads): forward through registers in K1's
+//   train_fwd_bwd_kernel  one workgroup of four waves per 32 batch rows.  Wave 0: forward through registers in K1's
 //       transposed formulation (rows on the lanes, the accumulator of layer l IS the B operand of layer l + 1), loss and
 //       dZ of the class layer in place, back-propagation dH_l = W_{l+1} dZ_{l+1} as the same kind of MFMA chain on a
-//       second, transposed packing of the weights, and the weight gradients dW_l = H_{l-1}^T dZ_l -- a contraction over
-//       the ROWS -- through wave-private LDS copies [neuron][row] of the activations and of dZ (stride 36 floats:
-//       conflict-free 16-byte operand reads).  No barrier (one wave), no atomics: every workgroup writes its partial
+//       second, transposed packing of the weights.  Waves 1-3: the weight gradients dW_l = H_{l-1}^T dZ_l -- a
+//       contraction over the ROWS -- from LDS copies [neuron][row] of the activations and of every layer's dZ (stride 36
+//       floats: conflict-free 16-byte operand reads).  Four barriers, no atomics: every workgroup writes its partial
 //       gradients to its own slab.
 //   train_adam_kernel     one thread per parameter: sums the slabs, adds beta W for h1..h3, TF-1 Adam (lr_t from the
 //       host in double, epsilon OUTSIDE the bias correction), and writes the weight in its three forms (canonical
@@ -123,10 +123,10 @@ __device__ __forceinline__ void grad_tile(const float *hs, const float *zs, int 
   for (int r = 0; r < 16; ++r) gw[static_cast<int64_t>(32 * it + neuron_of(r, half)) * n_out_pad + 32 * jt + li] = acc[r];
 }
 
-// db[32 t + n] = sum over the rows of dz: lane n < 32 adds its neuron's 32 values
-__device__ __forceinline__ void bias_grad(const float *zs, int tiles, int lane, float *gb) {
+// db[32 t + n] = sum over the rows of dz: lane n < 32 adds its neuron's 32 values (tiles t = first, first + step, ...)
+__device__ __forceinline__ void bias_grad(const float *zs, int tiles, int lane, float *gb, int first = 0, int step = 1) {
   if (lane < 32) {
-    for (int t = 0; t < tiles; ++t) {
+    for (int t = first; t < tiles; t += step) {
       const float *p = zs + (32 * t + lane) * kS;
       float s = 0.f;
 #pragma unroll
@@ -168,15 +168,23 @@ __device__ __forceinline__ void through_tanh(f32x16 &dh, const f32x16 &hd, const
   }
 }
 
+// Four waves per 32 rows (one per SIMD of a CU).  Wave 0 runs the dependent chain: forward, loss, dZ4, dH3 -> dZ3,
+// dH2 -> dZ2, dH1 -> dZ1.  Waves 1-3 compute every weight and bias gradient from the LDS copies as they appear, tiles
+// dealt round-robin -- 288 of the step's 800 MFMAs and all gradient stores leave the critical path; four barriers hand
+// the dZ copies over (one LDS buffer per layer, so wave 0 never waits for the others to finish reading).
 template <int MTC, bool DROP>
-__global__ __launch_bounds__(64) void train_fwd_bwd_kernel(const TrainParams p) {
+__global__ __launch_bounds__(256) void train_fwd_bwd_kernel(const TrainParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *const hs0 = lds;                       // x        [32][36]
   float *const hs1 = hs0 + 32 * kS;             // h1 (after dropout) [128][36]
   float *const hs2 = hs1 + kH1 * kS;            // h2       [64][36]
   float *const hs3 = hs2 + kH2 * kS;            // h3       [32][36]
-  float *const zs = hs3 + kH3 * kS;             // the current dZ [max(128, 32 MTC)][36]
-  const int lane = threadIdx.x, row = lane & 31, half = lane >> 5;
+  float *const zs4 = hs3 + kH3 * kS;            // dZ4 [32 MTC][36]
+  float *const zs3 = zs4 + 32 * MTC * kS;       // dZ3 [32][36]
+  float *const zs2 = zs3 + kH3 * kS;            // dZ2 [64][36]
+  float *const zs1 = zs2 + kH2 * kS;            // dZ1 [128][36]
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63, row = lane & 31, half = lane >> 5;
   const int64_t grow = static_cast<int64_t>(blockIdx.x) * 32 + row;   // global row of the batch
   float *const g = p.gpart + static_cast<int64_t>(blockIdx.x) * p.grad_floats;
   constexpr int CP = 32 * MTC;
@@ -188,6 +196,24 @@ __global__ __launch_bounds__(64) void train_fwd_bwd_kernel(const TrainParams p) 
   const float *const mk1 = DROP ? p.mask[0] + grow * kH1 : nullptr;
   const float *const mk2 = DROP ? p.mask[1] + grow * kH2 : nullptr;
   const float *const mk3 = DROP ? p.mask[2] + grow * kH3 : nullptr;
+
+  if (wave != 0) {   // ---------------- the three gradient waves: tiles dealt round-robin ----------------
+    constexpr int NH = 3;
+    const int hw = wave - 1;
+    __syncthreads();                                                   // dZ4 (and every hs copy) is in LDS
+    for (int jt = hw; jt < MTC; jt += NH) grad_tile(hs3, zs4, 0, jt, lane, g + oW4, CP);
+    bias_grad(zs4, MTC, lane, g + ob4, hw, NH);
+    __syncthreads();                                                   // dZ3
+    for (int it = hw; it < kT2; it += NH) grad_tile(hs2, zs3, it, 0, lane, g + oW3, kH3);
+    if (hw == 2) bias_grad(zs3, kT3, lane, g + ob3);
+    __syncthreads();                                                   // dZ2
+    for (int t = hw; t < kT1 * kT2; t += NH) grad_tile(hs1, zs2, t / kT2, t % kT2, lane, g + oW2, kH2);
+    bias_grad(zs2, kT2, lane, g + ob2, hw, NH);
+    __syncthreads();                                                   // dZ1
+    for (int jt = hw; jt < kT1; jt += NH) grad_tile(hs0, zs1, 0, jt, lane, g + oW1, kH1);
+    bias_grad(zs1, kT1, lane, g + ob1, hw, NH);
+    return;
+  }
 
   // ---------------- forward ----------------
   f32x16 xt[kT0];
@@ -259,17 +285,15 @@ __global__ __launch_bounds__(64) void train_fwd_bwd_kernel(const TrainParams p) 
       const float sm = c < p.n_classes ? __builtin_amdgcn_exp2f(t * 1.4426950408889634f) * inv_sum : 0.f;
       pz[mt][r] = (sm - (c == label ? 1.0f : 0.f)) * p.inv_batch * (1.0f - t * t);
     }
-    put_tile(zs, mt, pz[mt], row, half);
+    put_tile(zs4, mt, pz[mt], row, half);
   }
+  __syncthreads();   // hand dZ4 to the gradient wave
 
-  // ---------------- backward ----------------
-  // layer 4: dW4 = h3^T dz4, db4; dh3 = W4 dz4
+  // ---------------- backward: dH_l = W_{l+1} dZ_{l+1} ----------------
   f32x4 b3[kT2 * kT3 * 4];
   load_frags(p.wb[2], lane, b3);
   f32x4 b2[kT1 * kT2 * 4];
   load_frags(p.wb[1], lane, b2);
-  for (int jt = 0; jt < MTC; ++jt) grad_tile(hs3, zs, 0, jt, lane, g + oW4, CP);
-  bias_grad(zs, MTC, lane, g + ob4);
   f32x16 d3[kT3];
   {
     f32x16 acc;
@@ -277,11 +301,9 @@ __global__ __launch_bounds__(64) void train_fwd_bwd_kernel(const TrainParams p) 
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     d3[0] = chain<MTC>(pz, b4, acc);
     through_tanh<DROP>(d3[0], get_tile(hs3, 0, row, half), mk3, 0, half, p.inv_keep, keep);
-    put_tile(zs, 0, d3[0], row, half);
+    put_tile(zs3, 0, d3[0], row, half);
   }
-  // layer 3: dW3 = h2^T dz3 (2 x 1 tiles), db3; dh2 = W3 dz3
-  for (int it = 0; it < kT2; ++it) grad_tile(hs2, zs, it, 0, lane, g + oW3, kH3);
-  bias_grad(zs, kT3, lane, g + ob3);
+  __syncthreads();   // dZ3
   f32x16 d2[kT2];
 #pragma unroll
   for (int kt = 0; kt < kT2; ++kt) {
@@ -292,11 +314,8 @@ __global__ __launch_bounds__(64) void train_fwd_bwd_kernel(const TrainParams p) 
     through_tanh<DROP>(d2[kt], get_tile(hs2, kt, row, half), mk2, kt, half, p.inv_keep, keep);
   }
 #pragma unroll
-  for (int kt = 0; kt < kT2; ++kt) put_tile(zs, kt, d2[kt], row, half);
-  // layer 2: dW2 = h1^T dz2 (4 x 2 tiles), db2; dh1 = W2 dz2
-  for (int it = 0; it < kT1; ++it)
-    for (int jt = 0; jt < kT2; ++jt) grad_tile(hs1, zs, it, jt, lane, g + oW2, kH2);
-  bias_grad(zs, kT2, lane, g + ob2);
+  for (int kt = 0; kt < kT2; ++kt) put_tile(zs2, kt, d2[kt], row, half);
+  __syncthreads();   // dZ2
   f32x16 d1[kT1];
 #pragma unroll
   for (int kt = 0; kt < kT1; ++kt) {
@@ -307,10 +326,8 @@ __global__ __launch_bounds__(64) void train_fwd_bwd_kernel(const TrainParams p) 
     through_tanh<DROP>(d1[kt], get_tile(hs1, kt, row, half), mk1, kt, half, p.inv_keep, keep);
   }
 #pragma unroll
-  for (int kt = 0; kt < kT1; ++kt) put_tile(zs, kt, d1[kt], row, half);
-  // layer 1: dW1 = x^T dz1 (1 x 4 tiles), db1
-  for (int jt = 0; jt < kT1; ++jt) grad_tile(hs0, zs, 0, jt, lane, g + oW1, kH1);
-  bias_grad(zs, kT1, lane, g + ob1);
+  for (int kt = 0; kt < kT1; ++kt) put_tile(zs1, kt, d1[kt], row, half);
+  __syncthreads();   // dZ1
 }
 
 struct AdamParams {
@@ -437,14 +454,14 @@ using nnv::kH3;
 
 template <int MTC, bool DROP>
 void launch_one(const nnv::TrainParams &p, int n_wg, hipStream_t s) {
-  const int lds = (32 + kH1 + kH2 + kH3 + (MTC * 32 > kH1 ? MTC * 32 : kH1)) * nnv::kS * 4;
+  const int lds = (32 + kH1 + kH2 + kH3 + MTC * 32 + kH3 + kH2 + kH1) * nnv::kS * 4;   // hs0..hs3 + dZ4..dZ1
   static bool optin = false;   // > 64 KB of dynamic LDS must be opted into once per process and instantiation
   if (!optin) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nnv::train_fwd_bwd_kernel<MTC, DROP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     optin = true;
   }
-  hipLaunchKernelGGL((nnv::train_fwd_bwd_kernel<MTC, DROP>), dim3(n_wg), dim3(64), lds, s, p);
+  hipLaunchKernelGGL((nnv::train_fwd_bwd_kernel<MTC, DROP>), dim3(n_wg), dim3(256), lds, s, p);
 }
 template <int MTC>
 void launch_fwd_bwd(const nnv::TrainParams &p, int n_wg, hipStream_t s) {
