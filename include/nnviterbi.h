@@ -463,7 +463,9 @@ typedef struct nnv_train_desc {
 
 typedef struct nnv_train_handle nnv_train_handle;
 
-/* Replaces the variables + optimizer slots of run_network's graph (src/fnn_viterbi.py:538-567).  Synchronous. */
+/* Replaces the variables + optimizer slots of run_network's graph (src/fnn_viterbi.py:538-567).  Synchronous.
+ * A train handle is MUTABLE state (weights, Adam moments, the step count): one caller at a time, unlike the read-only
+ * decode handles; it belongs to the device that was current at creation (other device: NNV_ERR_INVALID_ARGUMENT). */
 int32_t nnv_train_create(const nnv_train_desc *net, nnv_train_handle **out);
 int32_t nnv_train_free(nnv_train_handle *h);
 

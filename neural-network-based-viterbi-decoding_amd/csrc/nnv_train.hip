@@ -452,21 +452,40 @@ using nnv::kH1;
 using nnv::kH2;
 using nnv::kH3;
 
+template <int MTC>
+constexpr int fwd_bwd_lds_bytes() { return (32 + kH1 + kH2 + kH3 + MTC * 32 + kH3 + kH2 + kH1) * nnv::kS * 4; }   // hs0..hs3 + dZ4..dZ1
+
 template <int MTC, bool DROP>
 void launch_one(const nnv::TrainParams &p, int n_wg, hipStream_t s) {
-  const int lds = (32 + kH1 + kH2 + kH3 + MTC * 32 + kH3 + kH2 + kH1) * nnv::kS * 4;   // hs0..hs3 + dZ4..dZ1
-  static bool optin = false;   // > 64 KB of dynamic LDS must be opted into once per process and instantiation
-  if (!optin) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nnv::train_fwd_bwd_kernel<MTC, DROP>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    optin = true;
-  }
-  hipLaunchKernelGGL((nnv::train_fwd_bwd_kernel<MTC, DROP>), dim3(n_wg), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((nnv::train_fwd_bwd_kernel<MTC, DROP>), dim3(n_wg), dim3(256), fwd_bwd_lds_bytes<MTC>(), s, p);
 }
 template <int MTC>
 void launch_fwd_bwd(const nnv::TrainParams &p, int n_wg, hipStream_t s) {
   if (p.mask[0]) launch_one<MTC, true>(p, n_wg, s);
   else launch_one<MTC, false>(p, n_wg, s);
+}
+
+// > 64 KB of dynamic LDS must be opted into per function AND per device: done by nnv_train_create on the handle's
+// device for both instantiations of its class width (idempotent, off the per-step path).
+template <int MTC>
+bool optin_lds() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(nnv::train_fwd_bwd_kernel<MTC, false>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, fwd_bwd_lds_bytes<MTC>()) == hipSuccess &&
+         hipFuncSetAttribute(reinterpret_cast<const void *>(nnv::train_fwd_bwd_kernel<MTC, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, fwd_bwd_lds_bytes<MTC>()) == hipSuccess;
+}
+bool optin_lds_for(int mtc) {
+  switch (mtc) {
+    case 1: return optin_lds<1>();
+    case 2: return optin_lds<2>();
+    case 3: return optin_lds<3>();
+    case 4: return optin_lds<4>();
+    case 5: return optin_lds<5>();
+    case 6: return optin_lds<6>();
+    case 7: return optin_lds<7>();
+    case 8: return optin_lds<8>();
+    default: return false;
+  }
 }
 
 nnv_status run_fwd_bwd(const nnv_train_handle *h, const float *x, const int32_t *labels, const float *const masks[3],
@@ -625,7 +644,8 @@ int32_t nnv_train_create(const nnv_train_desc *d, nnv_train_handle **out) {
     for (int m = 0; m < mr[l]; ++m) hw[h->off_b[l] + m] = d->b_host[l][m];
     fo += static_cast<int64_t>(K) * M;
   }
-  if (hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+  if (!optin_lds_for(h->mtc) ||
+      hipMemcpy(h->dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(h->dev);
     delete h;
     return NNV_ERR_HIP;
