@@ -447,9 +447,9 @@ int32_t nnv_seq2seq_forward_f32(const nnv_seq2seq_handle *h, const float *enc_in
  *   optional tf.nn.dropout after every hidden tanh                src/fnn_viterbi_mixed_snr.py:596-627
  * for the reference's architecture n_input -> 128 -> 64 -> 32 -> n_classes with n_input <= 32, n_classes <= 256 and a
  * batch of whole 32-row tiles (other shapes: NNV_ERR_UNSUPPORTED_SHAPE; the Python trainer then runs them through
- * PyTorch autograd).  One step = one forward/backward kernel (four waves per 32 rows: one on the dependent chain with
- * the activations in registers, three on the weight gradients through LDS) + one Adam kernel; no atomics, results
- * independent of the launch.
+ * PyTorch autograd).  One step = one forward/backward kernel (four waves per 32 rows, every layer's tiles dealt over
+ * them and handed over through LDS) + one Adam kernel; no atomics, every sum in a fixed order: results independent of
+ * the launch.
  * ------------------------------------------------------------------------ */
 typedef struct nnv_train_desc {
   int32_t n_input, n_classes, batch_size;

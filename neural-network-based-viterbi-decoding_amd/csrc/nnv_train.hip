@@ -6,19 +6,20 @@
 //
 // for the reference's architecture n_in -> 128 -> 64 -> 32 -> n_classes (src/fnn_viterbi.py:35-37) with n_in <= 32 and
 // n_classes <= 256 (block_length <= 8: the reference default 7 and BASELINE's 8).  A PyTorch-autograd step of this
-// network is ~45 tiny kernels, launch-bound at ~0.29 ms even inside a HIP graph; here a step is two launches, 37 us:
+// network is ~45 tiny kernels, launch-bound at ~0.29 ms even inside a HIP graph; here a step is two launches, 22 us:
 //
-//   train_fwd_bwd_kernel  one workgroup of four waves per 32 batch rows.  Wave 0: forward through registers in K1's
-//       transposed formulation (rows on the lanes, the accumulator of layer l IS the B operand of layer l + 1), loss and
-//       dZ of the class layer in place, back-propagation dH_l = W_{l+1} dZ_{l+1} as the same kind of MFMA chain on a
-//       second, transposed packing of the weights.  Waves 1-3: the weight gradients dW_l = H_{l-1}^T dZ_l -- a
-//       contraction over the ROWS -- from LDS copies [neuron][row] of the activations and of every layer's dZ (stride 36
-//       floats: conflict-free 16-byte operand reads).  Four barriers, no atomics: every workgroup writes its partial
-//       gradients to its own slab.
+//   train_fwd_bwd_kernel  one workgroup of four waves per 32 batch rows, all of them on the dependent chain: forward
+//       through registers in K1's transposed formulation (rows on the lanes, the accumulator of layer l IS the B operand
+//       of layer l + 1), loss and dZ of the class layer in place, back-propagation dH_l = W_{l+1} dZ_{l+1} as the same
+//       kind of MFMA chain on a second, transposed packing of the weights -- every layer's 32-wide tiles dealt over the
+//       waves and handed over through LDS in the register layout (see the kernel).  The weight gradients
+//       dW_l = H_{l-1}^T dZ_l -- a contraction over the ROWS -- come from second LDS copies [neuron][row] of the
+//       activations and of every layer's dZ (stride 36 floats: conflict-free 16-byte operand reads).  Five barriers, no
+//       atomics: every workgroup writes its partial gradients to its own slab.
 //   train_adam_kernel     one thread per parameter: sums the slabs, adds beta W for h1..h3, TF-1 Adam (lr_t from the
 //       host in double, epsilon OUTSIDE the bias correction), and writes the weight in its three forms (canonical
-//       [in][out], forward fragment order, backward fragment order); the last block to finish assembles the step's cost
-//       (cross-entropy parts + beta * regulariser).  Two launches per step.
+//       [in][out], forward fragment order, backward fragment order).  The cost's shares are added to running sums that
+//       nnv_train_export adds up; only a caller that wants per-step costs pays for their assembly by the last block.
 //
 // exact fp32 (v_mfma_f32_32x32x2_f32); summation order differs from a row-major matmul, the results are held to the
 // float64 restatement (oracle/train_oracle.py) at 1e-6 in tests/test_trainer.py.
@@ -48,12 +49,23 @@ struct TrainParams {
   const float *bias[4];      // padded to tiles
   float *gpart;              // [n_wg][grad_floats] partial gradients of this step
   int64_t grad_floats;
-  float *cost_part;          // [n_wg]
+  float *cost_part;          // [n_wg] this step's cross-entropy shares
+  double *cost_acc;          // nullable [n_wg]: their running sums over the steps (read and reset by nnv_train_export)
   const float *mask[3];      // nullable: [B][128], [B][64], [B][32] dropout masks (0/1) of this step
   float inv_keep, inv_batch;
 };
 
 __device__ __forceinline__ int neuron_of(int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); }
+
+#if defined(NNV_AB_BUILD) && defined(NNV_DIAG_TRAIN)   // diagnostic build only (tools/build_variant.sh): 100 MHz stamps of block 0
+__device__ unsigned long long g_train_diag[64];      // [16 wave + k]: k = 0 start, 1..5 behind barrier k, 6 end, 8..12 in front of barrier k - 7
+#define NNV_TRAIN_STAMP(slot)                                                                            \
+  do {                                                                                                   \
+    if (blockIdx.x == 0 && lane == 0) g_train_diag[slot] = __builtin_amdgcn_s_memrealtime();             \
+  } while (0)
+#else
+#define NNV_TRAIN_STAMP(slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ float fast_tanh(float z) {
   const float e = __builtin_amdgcn_exp2f(z * 2.8853900817779268f);
@@ -64,7 +76,7 @@ __device__ __forceinline__ float fast_tanh(float z) {
 // groups of a layer (N = tiles x k-tiles x 4, at most 32 = 128 registers) are requested together, then the layer's MFMA
 // chains run on them -- one exposed round trip per layer instead of one per tile.
 template <int N>
-__device__ __forceinline__ void load_frags(const float *frag, int lane, f32x4 (&a)[N]) {
+__device__ __forceinline__ void load_frags(const float *frag, int lane, f32x4 *a) {
 #pragma unroll
   for (int i = 0; i < N; ++i) a[i] = *reinterpret_cast<const f32x4 *>(frag + (i * 64 + lane) * 4);
   // keep the requests HERE: left alone, the scheduler sinks every load to just above its four MFMAs (to save
@@ -82,12 +94,13 @@ __device__ __forceinline__ f32x16 chain(const f32x16 (&in)[KT], const f32x4 *a, 
   return acc;
 }
 
-// tile (neurons 32 t .. 32 t + 31) back from its LDS copy [neuron][row] into the register layout
-__device__ __forceinline__ f32x16 get_tile(const float *s, int t, int row, int half) {
-  f32x16 v;
+// one k-tile: acc += W-tile (4 fragment groups) * in
+__device__ __forceinline__ f32x16 chain_one(const f32x16 &in, const f32x4 *a, f32x16 acc) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = s[(32 * t + neuron_of(r, half)) * kS + row];
-  return v;
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], in[4 * i + e], acc, 0, 0, 0);
+  return acc;
 }
 
 __device__ __forceinline__ f32x16 bias_tile(const float *b, int mt, int half) {
@@ -168,10 +181,47 @@ __device__ __forceinline__ void through_tanh(f32x16 &dh, const f32x16 &hd, const
   }
 }
 
-// Four waves per 32 rows (one per SIMD of a CU).  Wave 0 runs the dependent chain: forward, loss, dZ4, dH3 -> dZ3,
-// dH2 -> dZ2, dH1 -> dZ1.  Waves 1-3 compute every weight and bias gradient from the LDS copies as they appear, tiles
-// dealt round-robin -- 288 of the step's 800 MFMAs and all gradient stores leave the critical path; four barriers hand
-// the dZ copies over (one LDS buffer per layer, so wave 0 never waits for the others to finish reading).
+// Four waves per 32 rows (one per SIMD of a CU), ALL of them on the dependent chain: every layer's 32-wide output tiles
+// are dealt over the waves, which hand their tiles to each other through LDS in the REGISTER layout (xch_put / xch_get:
+// the lane that wrote a value is the lane that reads it back, 16-byte accesses, conflict-free) -- in the transposed
+// formulation a layer's accumulator IS the next layer's B operand, so no shuffle is needed on either side.
+//   P0  layer 1: tile w                                                   | barrier 1
+//   P1  layer 2: tile w (waves 0, 1)                                      | barrier 2
+//   P2  layer 3 (one tile: every wave computes it, cheaper than a hand-over); class tiles w, w + 4: tanh, exp,
+//       per-wave partial softmax sums                                     | barrier 3
+//   P3  softmax totals, loss, dZ4 of the own class tiles, the own tiles' share of dH3 (a split over K)  | barrier 4
+//   P4  dH3 = sum of the four shares (fixed order) -> dZ3; dZ2 tile w (waves 0, 1) while waves 2, 3 start on dW4
+//                                                                         | barrier 5
+//   P5  dZ1 tile w; then the weight and bias gradients from the [neuron][row] copies, dealt round-robin (dW1 tile w
+//       needs only this wave's own dZ1 tile: no sixth barrier)
+// Stamps of the one-wave chain this replaces (tools/diag_train_phases.py, round 5): 26.1 us on wave 0, 13.7 of them MFMA
+// issue, the other three waves waiting 18 us for dZ4.
+constexpr int kXT = 64 * 16;   // floats of one exchange tile
+
+__device__ __forceinline__ void xch_put(float *x, int t, const f32x16 &v, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    *reinterpret_cast<f32x4 *>(x + ((t * 4 + q) * 64 + lane) * 4) = o;
+  }
+}
+__device__ __forceinline__ f32x16 xch_get(const float *x, int t, int lane) {
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 i = *reinterpret_cast<const f32x4 *>(x + ((t * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * q + e] = i[e];
+  }
+  return v;
+}
+__device__ __forceinline__ f32x16 zero_tile() {
+  f32x16 v;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = 0.f;
+  return v;
+}
+
 template <int MTC, bool DROP>
 __global__ __launch_bounds__(256) void train_fwd_bwd_kernel(const TrainParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -183,11 +233,17 @@ __global__ __launch_bounds__(256) void train_fwd_bwd_kernel(const TrainParams p)
   float *const zs3 = zs4 + 32 * MTC * kS;       // dZ3 [32][36]
   float *const zs2 = zs3 + kH3 * kS;            // dZ2 [64][36]
   float *const zs1 = zs2 + kH2 * kS;            // dZ1 [128][36]
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  float *const xa = zs1 + kH1 * kS;             // exchange: h1 (4 tiles); later the waves' shares of dH3 (4 tiles)
+  float *const xb = xa + 4 * kXT;               // exchange: h2 (2 tiles)
+  float *const xc = xb + 2 * kXT;               // exchange: dZ2 (2 tiles)
+  float *const sm = xc + 2 * kXT;               // [4 waves][sum_e | p_label][32 rows]
+  const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, row = lane & 31, half = lane >> 5;
   const int64_t grow = static_cast<int64_t>(blockIdx.x) * 32 + row;   // global row of the batch
   float *const g = p.gpart + static_cast<int64_t>(blockIdx.x) * p.grad_floats;
   constexpr int CP = 32 * MTC;
+  constexpr int OWN = (MTC + 3) / 4;            // class tiles of a wave: w, w + 4
+  constexpr int GF = 256;                       // floats of one fragment group (64 lanes x 4)
   // offsets of the padded parameter arrays inside a gradient slab (the Adam kernel uses the same)
   constexpr int oW1 = 0, oW2 = oW1 + 32 * kH1, oW3 = oW2 + kH1 * kH2, oW4 = oW3 + kH2 * kH3, ob1 = oW4 + kH3 * CP,
                 ob2 = ob1 + kH1, ob3 = ob2 + kH2, ob4 = ob3 + kH3;
@@ -196,138 +252,179 @@ __global__ __launch_bounds__(256) void train_fwd_bwd_kernel(const TrainParams p)
   const float *const mk1 = DROP ? p.mask[0] + grow * kH1 : nullptr;
   const float *const mk2 = DROP ? p.mask[1] + grow * kH2 : nullptr;
   const float *const mk3 = DROP ? p.mask[2] + grow * kH3 : nullptr;
+  NNV_TRAIN_STAMP(16 * w + 0);
 
-  if (wave != 0) {   // ---------------- the three gradient waves: tiles dealt round-robin ----------------
-    constexpr int NH = 3;
-    const int hw = wave - 1;
-    __syncthreads();                                                   // dZ4 (and every hs copy) is in LDS
-    for (int jt = hw; jt < MTC; jt += NH) grad_tile(hs3, zs4, 0, jt, lane, g + oW4, CP);
-    bias_grad(zs4, MTC, lane, g + ob4, hw, NH);
-    __syncthreads();                                                   // dZ3
-    for (int it = hw; it < kT2; it += NH) grad_tile(hs2, zs3, it, 0, lane, g + oW3, kH3);
-    if (hw == 2) bias_grad(zs3, kT3, lane, g + ob3);
-    __syncthreads();                                                   // dZ2
-    for (int t = hw; t < kT1 * kT2; t += NH) grad_tile(hs1, zs2, t / kT2, t % kT2, lane, g + oW2, kH2);
-    bias_grad(zs2, kT2, lane, g + ob2, hw, NH);
-    __syncthreads();                                                   // dZ1
-    for (int jt = hw; jt < kT1; jt += NH) grad_tile(hs0, zs1, 0, jt, lane, g + oW1, kH1);
-    bias_grad(zs1, kT1, lane, g + ob1, hw, NH);
-    return;
-  }
-
-  // ---------------- forward ----------------
+  // ---------------- P0: layer 1, tile w ----------------
   f32x16 xt[kT0];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int k = neuron_of(r, half);
     xt[0][r] = k < p.n_in ? p.x[grow * p.n_in + k] : 0.f;
   }
-  put_tile(hs0, 0, xt[0], row, half);
-  f32x16 h1[kT1], h2[kT2], h3[kT3];
-  f32x4 f1[kT1 * kT0 * 4];
-  load_frags(p.wf[0], lane, f1);
-  f32x4 f2[kT2 * kT1 * 4];               // the NEXT layer's fragments are requested before this layer's MFMAs
-  load_frags(p.wf[1], lane, f2);
+  f32x4 f1[kT0 * 4];
+  load_frags<kT0 * 4>(p.wf[0] + w * (kT0 * 4 * GF), lane, f1);
+  f32x4 f2[kT1 * 4];                      // the NEXT phase's fragments are requested before this phase's MFMAs
+  if (w < kT2) load_frags<kT1 * 4>(p.wf[1] + w * (kT1 * 4 * GF), lane, f2);
+  if (w == 0) put_tile(hs0, 0, xt[0], row, half);
+  f32x16 h1w = chain<kT0>(xt, f1, bias_tile(p.bias[0], w, half));
+  activate<DROP>(h1w, mk1, w, half, p.inv_keep);
+  put_tile(hs1, w, h1w, row, half);
+  xch_put(xa, w, h1w, lane);
+  f32x4 f3[kT2 * 4];
+  load_frags<kT2 * 4>(p.wf[2], lane, f3);
+  NNV_TRAIN_STAMP(16 * w + 8);
+  __syncthreads();   // 1: h1
+  NNV_TRAIN_STAMP(16 * w + 1);
+
+  // ---------------- P1: layer 2, tile w (waves 0, 1) ----------------
+  f32x4 f4[OWN * 4], b4[OWN * 4];         // class layer, own tiles: forward and backward fragments
 #pragma unroll
-  for (int mt = 0; mt < kT1; ++mt) {
-    h1[mt] = chain<kT0>(xt, f1 + mt * kT0 * 4, bias_tile(p.bias[0], mt, half));
-    activate<DROP>(h1[mt], mk1, mt, half, p.inv_keep);
-    put_tile(hs1, mt, h1[mt], row, half);
+  for (int j = 0; j < OWN; ++j) {
+    const int mt = w + 4 * j;
+    if (mt < MTC) {
+      load_frags<4>(p.wf[3] + mt * (kT3 * 4 * GF), lane, f4 + 4 * j);
+      load_frags<4>(p.wb[3] + mt * (4 * GF), lane, b4 + 4 * j);
+    }
   }
-  f32x4 f3[kT3 * kT2 * 4];
-  load_frags(p.wf[2], lane, f3);
-  f32x4 f4[MTC * kT3 * 4];
-  load_frags(p.wf[3], lane, f4);
+  if (w < kT2) {
+    f32x16 h1[kT1];
 #pragma unroll
-  for (int mt = 0; mt < kT2; ++mt) {
-    h2[mt] = chain<kT1>(h1, f2 + mt * kT1 * 4, bias_tile(p.bias[1], mt, half));
-    activate<DROP>(h2[mt], mk2, mt, half, p.inv_keep);
-    put_tile(hs2, mt, h2[mt], row, half);
+    for (int t = 0; t < kT1; ++t) h1[t] = xch_get(xa, t, lane);
+    f32x16 a = chain<kT1>(h1, f2, bias_tile(p.bias[1], w, half));
+    activate<DROP>(a, mk2, w, half, p.inv_keep);
+    put_tile(hs2, w, a, row, half);
+    xch_put(xb, w, a, lane);
   }
+  NNV_TRAIN_STAMP(16 * w + 9);
+  __syncthreads();   // 2: h2
+  NNV_TRAIN_STAMP(16 * w + 2);
+
+  // ---------------- P2: layer 3 (every wave), class tiles w, w + 4 ----------------
+  f32x16 h2[kT2], h3[kT3];
+#pragma unroll
+  for (int t = 0; t < kT2; ++t) h2[t] = xch_get(xb, t, lane);
+  f32x4 b3[kT3 * 4], b2[kT2 * 4];         // backward fragments of dZ2 tile (w & 1) and of dZ1 tile w
+  load_frags<kT3 * 4>(p.wb[2] + (w & 1) * (kT3 * 4 * GF), lane, b3);
+  load_frags<kT2 * 4>(p.wb[1] + w * (kT2 * 4 * GF), lane, b2);
   h3[0] = chain<kT2>(h2, f3, bias_tile(p.bias[2], 0, half));
   activate<DROP>(h3[0], mk3, 0, half, p.inv_keep);
-  put_tile(hs3, 0, h3[0], row, half);
-
+  if (w == 0) put_tile(hs3, 0, h3[0], row, half);
   // class layer: p = tanh(z4); softmax cross-entropy ON p (the reference passes the tanh'd tensor as logits)
-  f32x16 pz[MTC];
+  f32x16 pz[OWN];
   const int label = p.labels[grow];
   float sum_e = 0.f, p_label = 0.f;
-  f32x4 b4[kT3 * MTC * 4];               // backward fragments of the class layer: requested before its forward MFMAs
-  load_frags(p.wb[3], lane, b4);
 #pragma unroll
-  for (int mt = 0; mt < MTC; ++mt) {
-    pz[mt] = chain<kT3>(h3, f4 + mt * kT3 * 4, bias_tile(p.bias[3], mt, half));
+  for (int j = 0; j < OWN; ++j) {
+    const int mt = w + 4 * j;
+    if (mt < MTC) {
+      pz[j] = chain<kT3>(h3, f4 + 4 * j, bias_tile(p.bias[3], mt, half));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = 32 * mt + neuron_of(r, half);
-      const float t = fast_tanh(pz[mt][r]);
-      pz[mt][r] = t;
-      if (c < p.n_classes) sum_e += __builtin_amdgcn_exp2f(t * 1.4426950408889634f);   // |t| <= 1: no max subtraction needed
-      p_label += c == label ? t : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * mt + neuron_of(r, half);
+        const float t = fast_tanh(pz[j][r]);
+        pz[j][r] = t;
+        if (c < p.n_classes) sum_e += __builtin_amdgcn_exp2f(t * 1.4426950408889634f);   // |t| <= 1: no max subtraction needed
+        p_label += c == label ? t : 0.f;
+      }
+    } else {
+      pz[j] = zero_tile();
     }
   }
   sum_e += __shfl_xor(sum_e, 32);
   p_label += __shfl_xor(p_label, 32);
-  float loss = __builtin_amdgcn_logf(sum_e) * 0.6931471805599453f - p_label;   // -log softmax(p)[label]
-  loss = half == 0 ? loss : 0.f;
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) loss += __shfl_xor(loss, off);
-  if (lane == 0) p.cost_part[blockIdx.x] = loss * p.inv_batch;
+  if (lane < 32) {
+    sm[(2 * w + 0) * 32 + row] = sum_e;
+    sm[(2 * w + 1) * 32 + row] = p_label;
+  }
+  NNV_TRAIN_STAMP(16 * w + 10);
+  __syncthreads();   // 3: softmax shares (and h3 in hs3)
+  NNV_TRAIN_STAMP(16 * w + 3);
 
+  // ---------------- P3: loss, dZ4 of the own tiles, their share of dH3 ----------------
+  sum_e = (sm[0 * 32 + row] + sm[2 * 32 + row]) + (sm[4 * 32 + row] + sm[6 * 32 + row]);
+  p_label = (sm[1 * 32 + row] + sm[3 * 32 + row]) + (sm[5 * 32 + row] + sm[7 * 32 + row]);
+  if (w == 0) {
+    float loss = __builtin_amdgcn_logf(sum_e) * 0.6931471805599453f - p_label;   // -log softmax(p)[label]
+    loss = half == 0 ? loss : 0.f;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) loss += __shfl_xor(loss, off);
+    if (lane == 0) {
+      p.cost_part[blockIdx.x] = loss * p.inv_batch;
+      if (p.cost_acc) p.cost_acc[blockIdx.x] += static_cast<double>(loss * p.inv_batch);   // own slot, stream-ordered steps
+    }
+  }
   // dZ4 = (softmax(p) - y) / B * (1 - p^2), in place
   const float inv_sum = 1.0f / sum_e;
+  f32x16 share = zero_tile();
 #pragma unroll
-  for (int mt = 0; mt < MTC; ++mt) {
+  for (int j = 0; j < OWN; ++j) {
+    const int mt = w + 4 * j;
+    if (mt < MTC) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = 32 * mt + neuron_of(r, half);
-      const float t = pz[mt][r];
-      const float sm = c < p.n_classes ? __builtin_amdgcn_exp2f(t * 1.4426950408889634f) * inv_sum : 0.f;
-      pz[mt][r] = (sm - (c == label ? 1.0f : 0.f)) * p.inv_batch * (1.0f - t * t);
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * mt + neuron_of(r, half);
+        const float t = pz[j][r];
+        const float sme = c < p.n_classes ? __builtin_amdgcn_exp2f(t * 1.4426950408889634f) * inv_sum : 0.f;
+        pz[j][r] = (sme - (c == label ? 1.0f : 0.f)) * p.inv_batch * (1.0f - t * t);
+      }
+      put_tile(zs4, mt, pz[j], row, half);
+      share = chain_one(pz[j], b4 + 4 * j, share);
     }
-    put_tile(zs4, mt, pz[mt], row, half);
   }
-  __syncthreads();   // hand dZ4 to the gradient wave
+  xch_put(xa, w, share, lane);            // xa's h1 tiles were last read before barrier 2
+  NNV_TRAIN_STAMP(16 * w + 11);
+  __syncthreads();   // 4: dZ4, the shares of dH3
+  NNV_TRAIN_STAMP(16 * w + 4);
 
-  // ---------------- backward: dH_l = W_{l+1} dZ_{l+1} ----------------
-  f32x4 b3[kT2 * kT3 * 4];
-  load_frags(p.wb[2], lane, b3);
-  f32x4 b2[kT1 * kT2 * 4];
-  load_frags(p.wb[1], lane, b2);
+  // ---------------- P4: dZ3 (every wave); dZ2 tile w (waves 0, 1); dW4's first tiles (waves 2, 3) ----------------
   f32x16 d3[kT3];
   {
-    f32x16 acc;
+    const f32x16 s0 = xch_get(xa, 0, lane), s1 = xch_get(xa, 1, lane), s2 = xch_get(xa, 2, lane), s3 = xch_get(xa, 3, lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    d3[0] = chain<MTC>(pz, b4, acc);
-    through_tanh<DROP>(d3[0], get_tile(hs3, 0, row, half), mk3, 0, half, p.inv_keep, keep);
-    put_tile(zs3, 0, d3[0], row, half);
+    for (int r = 0; r < 16; ++r) d3[0][r] = (s0[r] + s1[r]) + (s2[r] + s3[r]);
   }
-  __syncthreads();   // dZ3
-  f32x16 d2[kT2];
+  through_tanh<DROP>(d3[0], h3[0], mk3, 0, half, p.inv_keep, keep);
+  if (w < kT2) {
+    if (w == 0) put_tile(zs3, 0, d3[0], row, half);
+    f32x16 d2w = chain<kT3>(d3, b3, zero_tile());
+    f32x16 hsel;
 #pragma unroll
-  for (int kt = 0; kt < kT2; ++kt) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    d2[kt] = chain<kT3>(d3, b3 + kt * kT3 * 4, acc);
-    through_tanh<DROP>(d2[kt], get_tile(hs2, kt, row, half), mk2, kt, half, p.inv_keep, keep);
+    for (int r = 0; r < 16; ++r) hsel[r] = w == 0 ? h2[0][r] : h2[1][r];
+    through_tanh<DROP>(d2w, hsel, mk2, w, half, p.inv_keep, keep);
+    put_tile(zs2, w, d2w, row, half);
+    xch_put(xc, w, d2w, lane);
+  } else {
+    const int jt = w - kT2;                // class tiles 0, 1 (MTC permitting); the rest joins the pool of P5
+    if (jt < MTC) grad_tile(hs3, zs4, 0, jt, lane, g + oW4, CP);
+    bias_grad(zs4, MTC, lane, g + ob4, jt, 2);
   }
+  NNV_TRAIN_STAMP(16 * w + 12);
+  __syncthreads();   // 5: dZ3, dZ2
+  NNV_TRAIN_STAMP(16 * w + 5);
+
+  // ---------------- P5: dZ1 tile w, then the gradients ----------------
+  {
+    f32x16 d2[kT2];
 #pragma unroll
-  for (int kt = 0; kt < kT2; ++kt) put_tile(zs2, kt, d2[kt], row, half);
-  __syncthreads();   // dZ2
-  f32x16 d1[kT1];
-#pragma unroll
-  for (int kt = 0; kt < kT1; ++kt) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    d1[kt] = chain<kT2>(d2, b2 + kt * kT2 * 4, acc);
-    through_tanh<DROP>(d1[kt], get_tile(hs1, kt, row, half), mk1, kt, half, p.inv_keep, keep);
+    for (int t = 0; t < kT2; ++t) d2[t] = xch_get(xc, t, lane);
+    f32x16 d1w = chain<kT2>(d2, b2, zero_tile());
+    through_tanh<DROP>(d1w, h1w, mk1, w, half, p.inv_keep, keep);
+    put_tile(zs1, w, d1w, row, half);
   }
-#pragma unroll
-  for (int kt = 0; kt < kT1; ++kt) put_tile(zs1, kt, d1[kt], row, half);
-  __syncthreads();   // dZ1
+  // the pool: dW2 (8 tiles), dW3 (2), dW4 from class tile 2 on -- job k to wave k mod 4
+  constexpr int J2 = kT1 * kT2, J3 = J2 + kT2, JN = J3 + (MTC > 2 ? MTC - 2 : 0);
+  for (int k = w; k < JN; k += 4) {
+    if (k < J2) grad_tile(hs1, zs2, k / kT2, k % kT2, lane, g + oW2, kH2);
+    else if (k < J3) grad_tile(hs2, zs3, k - J2, 0, lane, g + oW3, kH3);
+    else grad_tile(hs3, zs4, 0, k - J3 + 2, lane, g + oW4, CP);
+  }
+  if (w >= 2) bias_grad(zs2, kT2, lane, g + ob2, w - 2, 2);
+  if (w == 1) bias_grad(zs3, kT3, lane, g + ob3);
+  // dW1 / db1 tile w: x (behind barrier 1) and this wave's OWN dZ1 tile -- a wave's LDS accesses complete in order
+  __builtin_amdgcn_wave_barrier();
+  grad_tile(hs0, zs1, 0, w, lane, g + oW1, kH1);
+  bias_grad(zs1, w + 1, lane, g + ob1, w, 4);
+  NNV_TRAIN_STAMP(16 * w + 6);
 }
 
 struct AdamParams {
@@ -341,7 +438,8 @@ struct AdamParams {
   float lr_t, beta1, beta2, eps, beta_reg;
   const float *cost_part;
   float *cost_out;   // nullable: cost of this step = sum of the workgroups' cross-entropy parts + beta * regulariser
-  float *cost_sum;   // nullable: running sum of the step costs (an epoch's mean is what the reference prints)
+  double *reg_acc;   // nullable [gridDim.x]: running sums of the blocks' regulariser shares (an epoch's mean cost is what
+                     // the reference prints: nnv_train_export adds the slots up, no per-step assembly)
   float *reg_part;   // [gridDim.x] the blocks' shares of the regulariser
   unsigned *done;    // blocks finished (the last one assembles the cost and resets it)
   int32_t apply;     // 0: gradients only (debug entry): w, m, v untouched, the summed gradient is written to gsum
@@ -394,8 +492,10 @@ __global__ __launch_bounds__(256) void train_adam_kernel(const AdamParams p) {
       }
     }
   }
-  // regulariser of the cost: the block's share to its own slot (no atomics on values: the sum order is fixed); the
-  // LAST block to finish (a ticket counter behind a fence) assembles the step's cost and resets the counter
+  // regulariser of the cost: the block's share to its own slot (no atomics on values: the sum order is fixed).  A
+  // training step only ADDS it to the block's running sum.  When the caller asks for this step's cost, the LAST block to
+  // finish (a ticket counter behind a fence) assembles it from the shares and resets the counter -- an atomic round trip
+  // and a second pass that the default path does not pay (8.7 -> 5.x us per launch).
   __shared__ float wave_reg[4];
   __shared__ unsigned ticket;
 #pragma unroll
@@ -403,10 +503,15 @@ __global__ __launch_bounds__(256) void train_adam_kernel(const AdamParams p) {
   if ((threadIdx.x & 63) == 0) wave_reg[threadIdx.x >> 6] = reg;
   __syncthreads();
   if (threadIdx.x == 0) {
-    p.reg_part[blockIdx.x] = (wave_reg[0] + wave_reg[1]) + (wave_reg[2] + wave_reg[3]);
-    __threadfence();
-    ticket = atomicAdd(p.done, 1u);
+    const float block_reg = (wave_reg[0] + wave_reg[1]) + (wave_reg[2] + wave_reg[3]);
+    if (p.reg_acc) p.reg_acc[blockIdx.x] += static_cast<double>(block_reg);
+    if (p.cost_out) {
+      p.reg_part[blockIdx.x] = block_reg;
+      __threadfence();
+      ticket = atomicAdd(p.done, 1u);
+    }
   }
+  if (!p.cost_out) return;   // kernel-uniform
   __syncthreads();
   if (ticket == gridDim.x - 1) {   // block-uniform: the last block sums the shares in parallel (fixed order per lane)
     __threadfence();
@@ -421,9 +526,7 @@ __global__ __launch_bounds__(256) void train_adam_kernel(const AdamParams p) {
     if ((threadIdx.x & 63) == 0) wave_reg[threadIdx.x >> 6] = t;
     __syncthreads();
     if (threadIdx.x == 0) {
-      const float total = (wave_reg[0] + wave_reg[1]) + (wave_reg[2] + wave_reg[3]);
-      if (p.cost_out) *p.cost_out = total;
-      if (p.cost_sum) *p.cost_sum += total;
+      *p.cost_out = (wave_reg[0] + wave_reg[1]) + (wave_reg[2] + wave_reg[3]);
       *p.done = 0u;
     }
   }
@@ -437,8 +540,9 @@ struct nnv_train_handle {
   int64_t grad_floats;
   float lr, beta_reg, keep_prob;
   int64_t step;              // Adam's t
-  float *dev;                // one allocation: w | m | v | wf[4] | wb[4] | gpart | gsum | cost_part | reg_part | cost_sum | done | scratch
-  float *w, *m, *v, *wf[4], *wb[4], *gpart, *gsum, *cost_part, *reg_part, *cost_sum, *cost_scratch;
+  float *dev;                // one allocation: w | m | v | wf[4] | wb[4] | gpart | gsum | cost_part | reg_part | done | scratch | cost_acc | reg_acc
+  float *w, *m, *v, *wf[4], *wb[4], *gpart, *gsum, *cost_part, *reg_part, *cost_scratch;
+  double *cost_acc, *reg_acc;   // [n_wg], [adam_blocks]: running sums since the last export
   unsigned *done;
   int32_t adam_blocks;
   int64_t off_w[4], off_b[4];   // inside a parameter array
@@ -453,7 +557,9 @@ using nnv::kH2;
 using nnv::kH3;
 
 template <int MTC>
-constexpr int fwd_bwd_lds_bytes() { return (32 + kH1 + kH2 + kH3 + MTC * 32 + kH3 + kH2 + kH1) * nnv::kS * 4; }   // hs0..hs3 + dZ4..dZ1
+constexpr int fwd_bwd_lds_bytes() {   // hs0..hs3 + dZ4..dZ1, 8 exchange tiles, the softmax shares
+  return ((32 + kH1 + kH2 + kH3 + MTC * 32 + kH3 + kH2 + kH1) * nnv::kS + 8 * nnv::kXT + 8 * 32) * 4;
+}
 
 template <int MTC, bool DROP>
 void launch_one(const nnv::TrainParams &p, int n_wg, hipStream_t s) {
@@ -489,7 +595,7 @@ bool optin_lds_for(int mtc) {
 }
 
 nnv_status run_fwd_bwd(const nnv_train_handle *h, const float *x, const int32_t *labels, const float *const masks[3],
-                       hipStream_t s) {
+                       bool training_step, hipStream_t s) {
   nnv::TrainParams p{};
   p.x = x;
   p.labels = labels;
@@ -503,6 +609,7 @@ nnv_status run_fwd_bwd(const nnv_train_handle *h, const float *x, const int32_t 
   p.gpart = h->gpart;
   p.grad_floats = h->grad_floats;
   p.cost_part = h->cost_part;
+  p.cost_acc = training_step ? h->cost_acc : nullptr;
   for (int l = 0; l < 3; ++l) p.mask[l] = masks ? masks[l] : nullptr;
   p.inv_keep = 1.0f / h->keep_prob;
   p.inv_batch = 1.0f / static_cast<float>(h->batch);
@@ -539,7 +646,7 @@ nnv_status run_adam(nnv_train_handle *h, bool apply, float *cost_out, hipStream_
   a.beta_reg = h->beta_reg;
   a.cost_part = h->cost_part;
   a.cost_out = cost_out;
-  a.cost_sum = apply ? h->cost_sum : nullptr;
+  a.reg_acc = apply ? h->reg_acc : nullptr;
   a.reg_part = h->reg_part;
   a.done = h->done;
   a.apply = apply ? 1 : 0;
@@ -603,7 +710,7 @@ int32_t nnv_train_create(const nnv_train_desc *d, nnv_train_handle **out) {
   h->grad_floats = off;
   const int64_t frag = h->off_b[0];                       // all four weight matrices, padded
   h->adam_blocks = static_cast<int32_t>((off + 255) / 256);
-  const int64_t total = 3 * off + 2 * frag + static_cast<int64_t>(h->n_wg) * off + off + h->n_wg + h->adam_blocks + 4 + 64;
+  const int64_t total = 3 * off + 2 * frag + static_cast<int64_t>(h->n_wg) * off + off + 3 * (h->n_wg + h->adam_blocks) + 4 + 64;
   if (hipMalloc(reinterpret_cast<void **>(&h->dev), total * sizeof(float)) != hipSuccess) {
     delete h;
     return NNV_ERR_OUT_OF_MEMORY;
@@ -618,9 +725,11 @@ int32_t nnv_train_create(const nnv_train_desc *d, nnv_train_handle **out) {
   h->gsum = q; q += off;
   h->cost_part = q; q += h->n_wg;
   h->reg_part = q; q += h->adam_blocks;
-  h->cost_sum = q; q += 1;
   h->done = reinterpret_cast<unsigned *>(q); q += 1;   // zero in the host image below: the kernel resets it itself
   h->cost_scratch = q; q += 1;
+  q += (q - h->dev) & 1;                               // doubles: 8-byte aligned (hipMalloc's base is)
+  h->cost_acc = reinterpret_cast<double *>(q); q += 2 * h->n_wg;
+  h->reg_acc = reinterpret_cast<double *>(q); q += 2 * h->adam_blocks;
   // host image: canonical (zero padded) + both fragment orders
   std::vector<float> host(static_cast<size_t>(total), 0.f);
   float *hw = host.data();
@@ -679,7 +788,7 @@ int32_t nnv_train_steps(nnv_train_handle *h, const float *x_dev, const int32_t *
       for (int l = 0; l < 3; ++l)
         mk[l] = masks_dev[l] ? masks_dev[l] + static_cast<int64_t>(t) * h->batch * widths[l] : nullptr;
     nnv_status st = run_fwd_bwd(h, x_dev + static_cast<int64_t>(t) * h->batch * h->n_in,
-                                labels_dev + static_cast<int64_t>(t) * h->batch, masks_dev ? mk : nullptr, s);
+                                labels_dev + static_cast<int64_t>(t) * h->batch, masks_dev ? mk : nullptr, true, s);
     if (st != NNV_OK) return st;
     st = run_adam(h, true, costs_dev ? costs_dev + t : nullptr, s);
     if (st != NNV_OK) return st;
@@ -695,7 +804,7 @@ int32_t nnv_train_gradients(nnv_train_handle *h, const float *x_dev, const int32
     const nnv_status dv = nnv::check_current_device(h->device);
     if (dv != NNV_OK) return dv;
   }
-  nnv_status st = run_fwd_bwd(h, x_dev, labels_dev, masks_dev, nullptr);
+  nnv_status st = run_fwd_bwd(h, x_dev, labels_dev, masks_dev, false, nullptr);
   if (st != NNV_OK) return st;
   st = run_adam(h, false, h->cost_scratch, nullptr);
   if (st != NNV_OK) return st;
@@ -730,12 +839,23 @@ int32_t nnv_train_export(const nnv_train_handle *h, float *const W_host[4], floa
       for (int m = 0; m < h->mreal[l]; ++m) b_host[l][m] = w[h->off_b[l] + m];
   }
   if (cost_sum_host) {   // sum of the step costs since the last export (the reference prints their mean per epoch), then reset
-    float c = 0.f;
-    if (hipMemcpy(&c, h->cost_sum, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return NNV_ERR_HIP;
-    *cost_sum_host = c;
-    if (hipMemset(h->cost_sum, 0, sizeof(float)) != hipSuccess) return NNV_ERR_HIP;
+    const size_t n = static_cast<size_t>(h->n_wg) + static_cast<size_t>(h->adam_blocks);   // the two arrays are adjacent
+    std::vector<double> acc(n);
+    if (hipMemcpy(acc.data(), h->cost_acc, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return NNV_ERR_HIP;
+    double ce = 0.0, reg = 0.0;
+    for (int i = 0; i < h->n_wg; ++i) ce += acc[static_cast<size_t>(i)];
+    for (int i = 0; i < h->adam_blocks; ++i) reg += acc[static_cast<size_t>(h->n_wg + i)];
+    *cost_sum_host = ce + static_cast<double>(h->beta_reg) * reg;
+    if (hipMemset(h->cost_acc, 0, n * sizeof(double)) != hipSuccess) return NNV_ERR_HIP;
   }
   return NNV_OK;
 }
+
+#if defined(NNV_AB_BUILD) && defined(NNV_DIAG_TRAIN)
+int32_t nnv_train_diag_read(unsigned long long *out64) {   // 64 stamps of the last step's block 0 (tools/diag_train_phases.py)
+  if (hipDeviceSynchronize() != hipSuccess) return NNV_ERR_HIP;
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(nnv::g_train_diag), 64 * sizeof(unsigned long long)) == hipSuccess ? NNV_OK : NNV_ERR_HIP;
+}
+#endif
 
 }  // extern "C"

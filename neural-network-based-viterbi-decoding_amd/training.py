@@ -219,9 +219,8 @@ class FNNTrainer:
 
 class NativeFNNTrainer:
     """The same training step as :class:`FNNTrainer`, as two hand-written HIP kernels per step (C ABI ``nnv_train_*``,
-    csrc/nnv_train.hip): forward + loss + backward in one launch (four waves per 32 rows: one on the dependent chain,
-    activations through registers; three on the weight gradients, through LDS), TF-1 Adam + re-packing of the weights in
-    a second.  ~45 launches of a PyTorch-autograd step become 2; the steps of an epoch are issued by ONE call.
+    csrc/nnv_train.hip): forward + loss + backward in one launch (four waves per 32 rows, every layer's
+    tiles dealt over them and handed over through LDS), TF-1 Adam + re-packing of the weights in a second.  ~45 launches of a PyTorch-autograd step become 2; the steps of an epoch are issued by ONE call.
 
     Eligible: the reference's architecture n_in -> 128 -> 64 -> 32 -> n_classes with n_in <= 32, n_classes <= 256, a
     batch size that is a multiple of 32, on an MI355X.  Labels are class indices (the position of the 1 in the
