@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NNV_ABI_VERSION 7 /* 7: + nnv_train_* (the training step as two kernels); prior: 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS; 6: + nnv_wide_set_path / _get_path, nnv_bitwise_set_path / _path_for (no environment switches any more) */
+#define NNV_ABI_VERSION 8 /* 8: + nnv_dense_train_* (the bit-wise / sliding-window decoders' training step); 7: + nnv_train_* (the training step as two kernels); prior: 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS; 6: + nnv_wide_set_path / _get_path, nnv_bitwise_set_path / _path_for (no environment switches any more) */
 #define NNV_MAX_LAYERS 4 /* dense layers incl. the output layer */
 #define NNV_MLP_MAX_INPUTS 32     /* nnv_mlp_*: row length n_input = 2 b (block_length <= 16); hidden widths: the first 1-3 of
                                      the reference's (128, 64, 32); other shapes: NNV_ERR_UNSUPPORTED_SHAPE -> nnv_wide_* */
@@ -491,6 +491,60 @@ int32_t nnv_train_gradients(nnv_train_handle *h, const float *x_dev, const int32
 /* Current weights to the host (the reference's Saver.save, src/fnn_viterbi_mixed_snr.py:782-784) and, if
  * cost_sum_host is not NULL, the sum of the step costs since the last export (reset by the call).  Synchronous. */
 int32_t nnv_train_export(const nnv_train_handle *h, float *const W_host[4], float *const b_host[4], double *cost_sum_host);
+
+/* ------------------------------------------------------------------------
+ * K8: the training step of the reference's bit-wise and sliding-window decoders, for a dense network of 1..5 layers of
+ * any width with the activation after EVERY layer (the output layer included):
+ *   cost = reduce_mean(sigmoid_cross_entropy_with_logits(logits=pred, labels=y)) + beta (l2_loss(h1) + l2_loss(h2)),
+ *   tf.train.AdamOptimizer(learning_rate).minimize(cost)
+ *   -- src/fnn_viterbi_bitwise.py:388-397,438-452 (1036 -> 30 -> 2 ReLU, batch 1000),
+ *      src/fnn_viterbi_seq_predict.py:404-412,475-489 (200 -> 500 x 4 -> 2 tanh, batch 100).
+ * One step = 2 L + 3 launches (stage the batch, L forward, loss, L backward, Adam) instead of ~60 PyTorch-autograd
+ * kernels; exact fp32; every sum in a fixed order.  Handles are mutable state: one caller at a time.
+ * ------------------------------------------------------------------------ */
+typedef struct nnv_dense_train_desc {
+  int32_t n_layers;             /* 1..5 */
+  int32_t dims[6];              /* n_input, the hidden widths, n_output (<= 32) */
+  int32_t activation;           /* nnv_activation */
+  int32_t batch_size;
+  float learning_rate, beta_regularization;
+  uint32_t reg_layer_mask;      /* bit l: tf.nn.l2_loss(W_l) is part of the cost (both references: layers 0 and 1) */
+  const float *W_host[5];       /* [in][out] row-major */
+  const float *b_host[5];
+  const float *extra_host;      /* nullable: variables that ONLY the regulariser names (the bit-wise decoder's unused h2,
+                                   src/fnn_viterbi_bitwise.py:388-397 vs :444-447): gradient beta * value, moved by Adam */
+  int64_t n_extra;
+} nnv_dense_train_desc;
+
+typedef struct nnv_dense_train_handle nnv_dense_train_handle;
+
+/* Replaces the variables + optimizer slots of train_and_evaluate's graph (src/fnn_viterbi_bitwise.py:429-452,
+ * src/fnn_viterbi_seq_predict.py:468-489).  Synchronous. */
+int32_t nnv_dense_train_create(const nnv_dense_train_desc *net, nnv_dense_train_handle **out);
+int32_t nnv_dense_train_free(nnv_dense_train_handle *h);
+
+/*
+ * Replaces n_steps iterations of sess.run([optimizer, cost], feed_dict={x: batch_x, y: batch_y})
+ * (src/fnn_viterbi_bitwise.py:475-494, src/fnn_viterbi_seq_predict.py:541-577).  Row m of step t is
+ * x_dev[t * step_stride + m * row_stride + k], k < n_input: a [rows][n_input] matrix has row_stride = n_input and
+ * step_stride = B * n_input; the sliding-window decoder's overlapping windows of ONE stream (window i = stream[2 i ..],
+ * src/fnn_viterbi_seq_predict.py:293-336) have row_stride = 2 and step_stride = 2 * B -- no window matrix is built.
+ *  labels_dev  [n_steps * B] int32 class index (the position of the 1 in the reference's one-hot batch_y)
+ *  costs_dev   nullable [n_steps] fp32 out: the cost of each batch BEFORE its update
+ * Asynchronous on `stream`.
+ */
+int32_t nnv_dense_train_steps(nnv_dense_train_handle *h, const float *x_dev, int64_t row_stride, int64_t step_stride,
+                              const int32_t *labels_dev, int32_t n_steps, float *costs_dev, void *stream);
+
+/* Parity / debug: cost and the gradients of ONE batch at the current values, no update.  Synchronous; host outputs in
+ * the reference's shapes; any pointer may be NULL. */
+int32_t nnv_dense_train_gradients(nnv_dense_train_handle *h, const float *x_dev, int64_t row_stride, const int32_t *labels_dev,
+                                  float *cost_host, float *const gW_host[5], float *const gb_host[5], float *gextra_host);
+
+/* Current values to the host (Saver.save, src/fnn_viterbi_bitwise.py:498-501) and, if cost_sum_host is not NULL, the sum
+ * of the step costs since the last export (reset by the call).  Synchronous. */
+int32_t nnv_dense_train_export(const nnv_dense_train_handle *h, float *const W_host[5], float *const b_host[5], float *extra_host,
+                               double *cost_sum_host);
 
 /*
  * Timing helper used by bench.py: launches nnv_mlp_decode_f32 `iters` times

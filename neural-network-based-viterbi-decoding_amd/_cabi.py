@@ -15,7 +15,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("NNV_LIB") or os.path.join(_PKG_DIR, "libnnviterbi_hip.so")
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 
-NNV_ABI_VERSION = 7
+NNV_ABI_VERSION = 8
 NNV_MAX_LAYERS = 4
 NNV_OK = 0
 NNV_CODE_57 = 0
@@ -32,6 +32,8 @@ EXPORTED_SYMBOLS = (
     "nnv_wide_prepack", "nnv_wide_free", "nnv_wide_workspace_bytes", "nnv_wide_decode_f32",
     "nnv_wide_set_path", "nnv_wide_get_path", "nnv_bitwise_set_path", "nnv_bitwise_path_for",
     "nnv_train_create", "nnv_train_free", "nnv_train_steps", "nnv_train_gradients", "nnv_train_export",
+    "nnv_dense_train_create", "nnv_dense_train_free", "nnv_dense_train_steps", "nnv_dense_train_gradients",
+    "nnv_dense_train_export",
     "nnv_seq2seq_prepack", "nnv_seq2seq_free", "nnv_seq2seq_forward_f32",
     "nnv_bitwise_prepack", "nnv_bitwise_prepack_ex", "nnv_bitwise_free", "nnv_bitwise_decode_f32",
 )
@@ -97,6 +99,22 @@ class TrainDesc(ctypes.Structure):
         ("keep_prob", ctypes.c_float),
         ("W_host", ctypes.c_void_p * 4),
         ("b_host", ctypes.c_void_p * 4),
+    ]
+
+
+class DenseTrainDesc(ctypes.Structure):
+    _fields_ = [
+        ("n_layers", ctypes.c_int32),
+        ("dims", ctypes.c_int32 * 6),
+        ("activation", ctypes.c_int32),
+        ("batch_size", ctypes.c_int32),
+        ("learning_rate", ctypes.c_float),
+        ("beta_regularization", ctypes.c_float),
+        ("reg_layer_mask", ctypes.c_uint32),
+        ("W_host", ctypes.c_void_p * 5),
+        ("b_host", ctypes.c_void_p * 5),
+        ("extra_host", ctypes.c_void_p),
+        ("n_extra", ctypes.c_int64),
     ]
 
 
@@ -230,6 +248,16 @@ def load_library() -> ctypes.CDLL:
     lib.nnv_train_gradients.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
     lib.nnv_train_export.restype = c.c_int32
     lib.nnv_train_export.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.nnv_dense_train_create.restype = c.c_int32
+    lib.nnv_dense_train_create.argtypes = [c.POINTER(DenseTrainDesc), c.POINTER(c.c_void_p)]
+    lib.nnv_dense_train_free.restype = c.c_int32
+    lib.nnv_dense_train_free.argtypes = [c.c_void_p]
+    lib.nnv_dense_train_steps.restype = c.c_int32
+    lib.nnv_dense_train_steps.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_int64, c.c_void_p, c.c_int32, c.c_void_p, c.c_void_p]
+    lib.nnv_dense_train_gradients.restype = c.c_int32
+    lib.nnv_dense_train_gradients.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.nnv_dense_train_export.restype = c.c_int32
+    lib.nnv_dense_train_export.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
     if lib.nnv_abi_version() != NNV_ABI_VERSION:
         raise NNViterbiError(
             f"ABI mismatch: library {lib.nnv_abi_version()} != binding {NNV_ABI_VERSION}")

@@ -72,22 +72,19 @@ def generate_info_sequence(block_length: int) -> np.ndarray:
                        dtype=np.int32, count=block_length)
 
 
-def _delayed(u: np.ndarray, d: int) -> np.ndarray:
-    """u shifted right by d positions along the last axis, zero filled
-    (the encoder register starts in the all-zero state)."""
-    if d == 0:
-        return u
-    out = np.zeros_like(u)
-    if d < u.shape[-1]:
-        out[..., d:] = u[..., :-d]
-    return out
-
-
 def _conv_parity(u: np.ndarray, taps) -> np.ndarray:
-    acc = np.zeros(u.shape, dtype=np.int64)
+    """Parity of u[i - d] summed over the taps d (zero register at the start), uint8.  The parity of a sum of
+    integers is the XOR of their low bits, so the shifted copies are XORed in place as bytes: no int64
+    temporaries (at the bit-wise decoder's 300,000 x 518 rows they were 1.2 GB each and the whole cost)."""
+    low = (np.asarray(u) & 1).astype(np.uint8)
+    acc = np.zeros(low.shape, dtype=np.uint8)
+    n = low.shape[-1]
     for d in taps:
-        acc += _delayed(u, d)
-    return acc % 2
+        if d == 0:
+            acc ^= low
+        elif d < n:
+            acc[..., d:] ^= low[..., :n - d]
+    return acc
 
 
 _TAPS_133 = (0, 2, 3, 5, 6)
@@ -98,7 +95,9 @@ def encode_133171_batch(bits: np.ndarray) -> np.ndarray:
     """Rows of ``bits`` [..., L] encoded independently from zero state with the
     (133,171) rate-1/2 K=7 code; output [..., 2L] int32, pair i = (g133, g171).
     Vectorised twin of :func:`encode_133171`."""
-    u = np.asarray(bits).astype(np.int64)
+    u = np.asarray(bits)
+    if not np.issubdtype(u.dtype, np.integer):
+        u = u.astype(np.int64)
     if u.shape[-1] < 6:
         raise IndexError("index 5 is out of bounds: encode_133171 needs >= 6 bits")
     out = np.empty(u.shape[:-1] + (2 * u.shape[-1],), dtype=np.int32)
@@ -109,7 +108,9 @@ def encode_133171_batch(bits: np.ndarray) -> np.ndarray:
 
 def encode_57_batch(bits: np.ndarray) -> np.ndarray:
     """Vectorised twin of :func:`encode_57` (quirks included)."""
-    u = np.asarray(bits).astype(np.int64)
+    u = np.asarray(bits)
+    if not np.issubdtype(u.dtype, np.integer) or u.dtype.itemsize < 8:
+        u = u.astype(np.int64)                    # the two start-up outputs below are sums, not parities
     if u.shape[-1] < 2:
         raise IndexError("index 1 is out of bounds: encode_57 needs >= 2 bits")
     out = np.empty(u.shape[:-1] + (2 * u.shape[-1],), dtype=np.int32)

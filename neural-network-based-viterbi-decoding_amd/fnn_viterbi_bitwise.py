@@ -98,8 +98,10 @@ def generate_input_vectors(length: int, number: int) -> np.ndarray:
 
 
 def _encode_rows(info_seq: np.ndarray, state: int) -> np.ndarray:
-    prefix = np.broadcast_to(extract_state_bits(state), (info_seq.shape[0], 6))
-    return _fv.encode_133171_batch(np.concatenate([prefix, info_seq.astype(np.int64)], axis=1))
+    rows = np.empty((info_seq.shape[0], 6 + info_seq.shape[1]), dtype=np.uint8)      # 0/1 bits: bytes, not int64
+    rows[:, :6] = extract_state_bits(state)
+    rows[:, 6:] = info_seq
+    return _fv.encode_133171_batch(rows)
 
 
 def generate_training_data(config: BitwiseDecoderConfig) -> Tuple[np.ndarray, np.ndarray]:
@@ -119,8 +121,13 @@ def generate_test_data(config: BitwiseDecoderConfig) -> Tuple[np.ndarray, np.nda
     info_seq = generate_input_vectors(config.block_length, config.test_size)
     encoded = _encode_rows(info_seq, config.starting_state)
     test_sigma = config.sigma_vec[config.test_snr_index]
-    for i in range(config.test_size):
-        encoded[i, :] = modulate_awgn(encoded[i, :], test_sigma)
+    # one np.random.normal call per row in the reference; consecutive calls fill from the same Gaussian stream as one
+    # call over several rows, so the rows are drawn 8,192 at a time (identical values, ~30x fewer Python round trips)
+    for lo in range(0, config.test_size, 8192):
+        blk = encoded[lo:lo + 8192]
+        sym = blk.astype(np.float32)
+        sym[sym == 0] = -1
+        blk[...] = sym + np.random.normal(0, test_sigma, blk.shape)      # float64 -> int32: truncation toward zero (F12)
     return info_seq, encoded
 
 
@@ -234,6 +241,28 @@ def train_and_evaluate(config: BitwiseDecoderConfig, train_info: np.ndarray, tra
     import torch
     dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     weights, biases = initialize_weights(config)
+    from .training import NativeDenseTrainer
+    bs = int(config.batch_size)
+    total_batch = int(config.training_size / bs)
+    if total_batch > 0 and NativeDenseTrainer.eligible(active_layers(weights, biases)[0], config.n_output):
+        # K8 (csrc/nnv_dense_train.hip): the step as 7 hand-written launches.  The regulariser names h1 and h2 (:444-447);
+        # h2 is a variable the network never uses (:388-397): it only decays, as an "extra" of the trainer.
+        Ws, Bs = active_layers(weights, biases)
+        nt = NativeDenseTrainer(Ws, Bs, "relu", config.learning_rate, config.beta_regularization, bs,
+                                reg_layers=(0,), extra=[weights["h2"]])
+        n = total_batch * bs
+        x_all = torch.as_tensor(np.asarray(train_encoded[:n], dtype=np.float32), device=nt.device).contiguous()
+        lab = torch.as_tensor(np.asarray(train_info)[:n, config.bit_position].astype(np.int32), device=nt.device).contiguous()
+        for epoch in range(int(config.training_epochs)):
+            nt.steps(x_all, lab, total_batch)
+            if epoch % config.display_step == 0:
+                print(f"Epoch: {epoch + 1:04d} | cost = {nt.export(want_cost_sum=True)[3] / total_batch:.9f}")
+        Ws, Bs, extras = nt.export()
+        nt.close()
+        del x_all, lab
+        weights = dict(weights, h1=Ws[0], out=Ws[1], h2=extras[0])
+        biases = dict(biases, b1=Bs[0], out=Bs[1])
+        return _finish_training(config, weights, biases, test_info, test_encoded, model_save_path)
     W = {k: torch.tensor(weights[k], device=dev, requires_grad=True) for k in _W_KEYS}
     B = {k: torch.tensor(biases[k], device=dev, requires_grad=True) for k in _B_KEYS}
     x_all = torch.as_tensor(np.asarray(train_encoded, dtype=np.float32), device=dev)
@@ -242,8 +271,6 @@ def train_and_evaluate(config: BitwiseDecoderConfig, train_info: np.ndarray, tra
     params = list(W.values()) + list(B.values())
     from .training import GraphedStep, TFAdam
     opt = TFAdam(params, lr=config.learning_rate)     # tf.train.AdamOptimizer (src/fnn_viterbi_bitwise.py:451), TF-1's update rule
-    bs = int(config.batch_size)
-    total_batch = int(config.training_size / bs)
 
     def step(xb, yb):
         h = torch.relu(xb @ W["h1"] + B["b1"])
@@ -262,9 +289,13 @@ def train_and_evaluate(config: BitwiseDecoderConfig, train_info: np.ndarray, tra
             avg_cost += run(x_all[i * bs:(i + 1) * bs], y_all[i * bs:(i + 1) * bs]) / max(total_batch, 1)
         if epoch % config.display_step == 0:
             print(f"Epoch: {epoch + 1:04d} | cost = {float(avg_cost):.9f}")
-    print("Optimization Finished!")
     weights = {k: v.detach().cpu().numpy().copy() for k, v in W.items()}
     biases = {k: v.detach().cpu().numpy().copy() for k, v in B.items()}
+    return _finish_training(config, weights, biases, test_info, test_encoded, model_save_path)
+
+
+def _finish_training(config, weights, biases, test_info, test_encoded, model_save_path):
+    print("Optimization Finished!")
     if model_save_path:
         save_model(model_save_path, weights, biases)
         print(f"Model saved to {model_save_path}")

@@ -252,14 +252,29 @@ def _train(config: SequentialDecoderConfig, train_info, train_coded, weights, bi
     (src/fnn_viterbi_seq_predict.py:470-487,541-577).  Plain PyTorch autograd."""
     import torch
     dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    from .training import NativeDenseTrainer
+    bs, win = int(config.batch_size), int(config.window_length)
+    total_batch = int(config.total_training_instances / bs)
+    if total_batch > 0 and NativeDenseTrainer.eligible([weights[k] for k in _W_KEYS], config.n_output):
+        # K8 (csrc/nnv_dense_train.hip): the step as 13 hand-written launches; window i = stream[2 i : 2 i + win] is
+        # addressed inside the staging kernel (row stride 2), so no [instances, win] matrix exists
+        nt = NativeDenseTrainer([weights[k] for k in _W_KEYS], [biases[k] for k in _B_KEYS], "tanh", config.learning_rate,
+                                config.beta_regularization, bs, reg_layers=(0, 1))
+        stream = torch.as_tensor(np.asarray(train_coded)[0].astype(np.float32), device=nt.device).contiguous()
+        lab = torch.as_tensor(np.asarray(train_info)[0, :total_batch * bs].astype(np.int32), device=nt.device).contiguous()
+        for epoch in range(int(config.training_epochs)):
+            nt.steps(stream, lab, total_batch, row_stride=2, step_stride=2 * bs)
+            if epoch % config.display_step == 0:
+                print(f"Epoch: {epoch + 1:04d} | cost = {nt.export(want_cost_sum=True)[3] / total_batch:.9f}")
+        Ws, Bs, _ = nt.export()
+        nt.close()
+        return dict(zip(_W_KEYS, Ws)), dict(zip(_B_KEYS, Bs))
     W = [torch.tensor(weights[k], dtype=torch.float32, device=dev, requires_grad=True) for k in _W_KEYS]
     B = [torch.tensor(biases[k], dtype=torch.float32, device=dev, requires_grad=True) for k in _B_KEYS]
     stream = torch.as_tensor(np.asarray(train_coded)[0].astype(np.float32), device=dev)
     bits = torch.as_tensor(np.asarray(train_info)[0].astype(np.int64), device=dev)
     from .training import GraphedStep, TFAdam
     opt = TFAdam(W + B, lr=config.learning_rate)      # tf.train.AdamOptimizer (src/fnn_viterbi_seq_predict.py:488), TF-1's update rule
-    bs, win = int(config.batch_size), int(config.window_length)
-    total_batch = int(config.total_training_instances / bs)
     windows = stream.unfold(0, win, 2)                      # window i = stream[2i : 2i + win]
 
     def step(xb, bb):

@@ -341,6 +341,127 @@ class NativeFNNTrainer:
         return out + (float(csum.value),) if want_cost_sum else out
 
 
+class NativeDenseTrainer:
+    """The training step of the reference's bit-wise and sliding-window decoders as 2 L + 3 hand-written HIP launches
+    per step (C ABI ``nnv_dense_train_*``, csrc/nnv_dense_train.hip) instead of ~60 PyTorch-autograd kernels: a dense
+    network of 1..5 layers with the activation after EVERY layer, mean sigmoid cross-entropy on the activated outputs,
+    beta * l2_loss of the layers in ``reg_layers``, TF-1 Adam (src/fnn_viterbi_bitwise.py:388-397,438-452;
+    src/fnn_viterbi_seq_predict.py:404-412,475-489).  ``extra`` holds variables that only the regulariser names (the
+    bit-wise decoder's unused ``h2``).  Labels are class indices.  Rows of a step may be overlapping windows of one
+    stream (``row_stride``).  Checked against oracle/dense_train_oracle.py (tests/test_dense_trainer.py)."""
+
+    ACT = {"tanh": 0, "relu": 1}
+
+    @staticmethod
+    def eligible(Ws, n_out: int) -> bool:
+        return torch.cuda.is_available() and 1 <= len(Ws) <= 5 and n_out <= 32 and os.environ.get("NNV_TRAINER") != "autograd"
+
+    def __init__(self, Ws, bs, activation: str, learning_rate: float, beta_regularization: float, batch_size: int,
+                 reg_layers=(0, 1), extra=None, device=None):
+        import ctypes
+        from . import _cabi
+        self._cabi, self._ctypes = _cabi, ctypes
+        self._lib = _cabi.load_library()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)
+        Ws = [np.ascontiguousarray(np.asarray(w), dtype=np.float32) for w in Ws]
+        bs = [np.ascontiguousarray(np.asarray(b), dtype=np.float32).reshape(-1) for b in bs]
+        self.shapes = [w.shape for w in Ws]
+        self.batch_size, self.n_input, self.n_out = int(batch_size), Ws[0].shape[0], Ws[-1].shape[1]
+        self.extra_shapes = [np.asarray(e).shape for e in (extra or [])]
+        ex = np.concatenate([np.asarray(e, np.float32).reshape(-1) for e in extra]) if extra else np.zeros(0, np.float32)
+        self.n_extra = int(ex.size)
+        d = _cabi.DenseTrainDesc()
+        d.n_layers = len(Ws)
+        for i, w in enumerate(Ws):
+            d.dims[i], d.dims[i + 1] = w.shape
+            d.W_host[i], d.b_host[i] = w.ctypes.data, bs[i].ctypes.data
+        d.activation, d.batch_size = self.ACT[activation], self.batch_size
+        d.learning_rate, d.beta_regularization = float(learning_rate), float(beta_regularization)
+        d.reg_layer_mask = sum(1 << l for l in reg_layers if l < len(Ws))
+        d.extra_host, d.n_extra = (ex.ctypes.data if self.n_extra else None), self.n_extra
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _cabi.check(self._lib.nnv_dense_train_create(ctypes.byref(d), ctypes.byref(h)), "nnv_dense_train_create")
+        self._handle = h
+
+    def close(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            self._lib.nnv_dense_train_free(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, x, labels, n_steps, row_stride, step_stride):
+        need = (n_steps - 1) * step_stride + (self.batch_size - 1) * row_stride + self.n_input
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() >= need):
+            raise ValueError(f"x must be a contiguous float32 CUDA tensor of at least {need} elements")
+        if not (labels.is_cuda and labels.dtype == torch.int32 and labels.is_contiguous()
+                and labels.numel() >= n_steps * self.batch_size):
+            raise ValueError(f"labels must be a contiguous int32 CUDA tensor of at least {n_steps * self.batch_size} class indices")
+
+    def steps(self, x: torch.Tensor, labels: torch.Tensor, n_steps: int, row_stride: int = None, step_stride: int = None,
+              want_costs: bool = False):
+        """``n_steps`` consecutive batches, stream-ordered, one C call.  Default strides: ``x`` is [rows, n_input]."""
+        row_stride = self.n_input if row_stride is None else int(row_stride)
+        step_stride = self.batch_size * row_stride if step_stride is None else int(step_stride)
+        self._check(x, labels, n_steps, row_stride, step_stride)
+        costs = torch.empty(n_steps, dtype=torch.float32, device=self.device) if want_costs else None
+        with torch.cuda.device(self.device):
+            st = self._lib.nnv_dense_train_steps(self._handle, x.data_ptr(), row_stride, step_stride, labels.data_ptr(), int(n_steps),
+                                                 None if costs is None else costs.data_ptr(),
+                                                 self._ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        self._cabi.check(st, "nnv_dense_train_steps")
+        return costs
+
+    def _out_arrays(self):
+        Ws = [np.zeros(s, np.float32) for s in self.shapes]
+        bs = [np.zeros(s[1], np.float32) for s in self.shapes]
+        pw = (self._ctypes.c_void_p * 5)(*[g.ctypes.data for g in Ws])
+        pb = (self._ctypes.c_void_p * 5)(*[g.ctypes.data for g in bs])
+        ex = np.zeros(self.n_extra, np.float32)
+        return Ws, bs, ex, pw, pb
+
+    def _split_extra(self, ex):
+        out, at = [], 0
+        for s in self.extra_shapes:
+            n = int(np.prod(s))
+            out.append(ex[at:at + n].reshape(s).copy())
+            at += n
+        return out
+
+    def gradients(self, xb: torch.Tensor, labels: torch.Tensor, row_stride: int = None):
+        """(cost, dWs, dbs, dextras) of one batch at the current values; no update (parity tests)."""
+        row_stride = self.n_input if row_stride is None else int(row_stride)
+        self._check(xb, labels, 1, row_stride, 0)
+        gW, gb, ex, pw, pb = self._out_arrays()
+        cost = self._ctypes.c_float(0.0)
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream(self.device).synchronize()
+            st = self._lib.nnv_dense_train_gradients(self._handle, xb.data_ptr(), row_stride, labels.data_ptr(),
+                                                     self._ctypes.byref(cost), self._ctypes.cast(pw, self._ctypes.c_void_p),
+                                                     self._ctypes.cast(pb, self._ctypes.c_void_p),
+                                                     ex.ctypes.data if self.n_extra else None)
+        self._cabi.check(st, "nnv_dense_train_gradients")
+        return float(cost.value), gW, gb, self._split_extra(ex)
+
+    def export(self, want_cost_sum: bool = False):
+        """(Ws, bs, extras[, sum of the step costs since the last export])."""
+        Ws, bs, ex, pw, pb = self._out_arrays()
+        csum = self._ctypes.c_double(0.0)
+        with torch.cuda.device(self.device):
+            st = self._lib.nnv_dense_train_export(self._handle, self._ctypes.cast(pw, self._ctypes.c_void_p),
+                                                  self._ctypes.cast(pb, self._ctypes.c_void_p),
+                                                  ex.ctypes.data if self.n_extra else None,
+                                                  self._ctypes.byref(csum) if want_cost_sum else None)
+        self._cabi.check(st, "nnv_dense_train_export")
+        out = (Ws, bs, self._split_extra(ex))
+        return out + (float(csum.value),) if want_cost_sum else out
+
+
 def train_network(config, training_set: np.ndarray, training_labels: np.ndarray,
                   weights: Dict[str, np.ndarray], biases: Dict[str, np.ndarray],
                   use_dropout: bool = False, keep_prob: float = 0.5,
