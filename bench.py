@@ -405,6 +405,33 @@ def next_row_paths(dev, steps: int):
                                                    "algorithmic_tflops": 6 * macs * bs_t / (us_native * 1e-6) / 1e12,
                                                    "cost_first_last": [float(costs[0].item()), float(costs[-1].item())]},
                             "autograd_from_hip_graph": {"us_per_step": us_auto, "graph_captured": bool(run.captured)}}
+    del xt, lt, yt
+    # SURVEY.md section 8(f) ranks 2 and 4, the training side: the bit-wise and the sliding-window decoders' step
+    # (src/fnn_viterbi_bitwise.py:438-452 batch 1000, src/fnn_viterbi_seq_predict.py:475-489 batch 100 over windows of one
+    # stream) through K8 (csrc/nnv_dense_train.hip: 2 L + 1 launches per step)
+    dense = {}
+    for name, dims, act, bs_d, steps_d, stride in (("bitwise_1036_30_2_relu", [1036, 30, 2], "relu", 1000, 300, None),
+                                                   ("sliding_window_200_500x4_2_tanh", [200, 500, 500, 500, 500, 2], "tanh", 100, 1000, 2)):
+        rng = np.random.RandomState(0)
+        Wd = [(rng.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+        Bd = [np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 1)]
+        rs = dims[0] if stride is None else stride
+        flat = torch.randn(((steps_d * bs_d - 1) * rs + dims[0],), device=dev, generator=g)
+        labd = torch.randint(0, 2, (steps_d * bs_d,), device=dev, dtype=torch.int32, generator=g)
+        dt_ = training.NativeDenseTrainer(Wd, Bd, act, 2e-4, 1e-4, bs_d, reg_layers=(0, 1) if len(dims) > 3 else (0,), device=dev)
+        dt_.steps(flat, labd, steps_d, row_stride=rs, step_stride=bs_d * rs)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        cd = dt_.steps(flat, labd, steps_d, row_stride=rs, step_stride=bs_d * rs, want_costs=True)
+        torch.cuda.synchronize(dev)
+        us_d = (time.perf_counter() - t0) / steps_d * 1e6
+        dt_.close()
+        macs_d = sum(int(np.prod(w.shape)) for w in Wd)
+        dense[name] = {"batch": bs_d, "launches_per_step": 2 * (len(dims) - 1) + 1, "us_per_step": us_d,
+                       "algorithmic_tflops": 6 * macs_d * bs_d / (us_d * 1e-6) / 1e12,
+                       "cost_first_last": [float(cd[0].item()), float(cd[-1].item())]}
+        del flat, labd
+    out["dense_training_steps_K8"] = dense
     return out
 
 

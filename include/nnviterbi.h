@@ -499,7 +499,8 @@ int32_t nnv_train_export(const nnv_train_handle *h, float *const W_host[4], floa
  *   tf.train.AdamOptimizer(learning_rate).minimize(cost)
  *   -- src/fnn_viterbi_bitwise.py:388-397,438-452 (1036 -> 30 -> 2 ReLU, batch 1000),
  *      src/fnn_viterbi_seq_predict.py:404-412,475-489 (200 -> 500 x 4 -> 2 tanh, batch 100).
- * One step = 2 L + 3 launches (stage the batch, L forward, loss, L backward, Adam) instead of ~60 PyTorch-autograd
+ * One step = 2 L + 1 launches (L forward with the loss in the last one's epilogue, L backward, Adam + staging of the
+ * next batch) instead of ~60 PyTorch-autograd
  * kernels; exact fp32; every sum in a fixed order.  Handles are mutable state: one caller at a time.
  * ------------------------------------------------------------------------ */
 typedef struct nnv_dense_train_desc {

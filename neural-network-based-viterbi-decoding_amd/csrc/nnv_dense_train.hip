@@ -9,15 +9,17 @@
 //
 // Batches are small (the reference: 1000 rows x 1036 -> 30 -> 2, and 100 rows x 200 -> 500 x 4 -> 2), so a step is
 // launch- and latency-shaped: PyTorch autograd spends ~60 tiny kernels on it (0.24 / 0.40 ms per step replayed from a HIP
-// graph, the sliding-window loop bound by the HOST's graph launches).  Here a step is 2 L + 3 launches:
+// graph, the sliding-window loop bound by the HOST's graph launches).  Here a step is 2 L + 1 launches:
 //
 //   stage      the batch's rows (row stride and step stride are arguments: the sliding-window rows are overlapping
 //              windows of ONE stream, window i = stream[2 i .. 2 i + 200)) into a zero-padded [Bp][Kp] tile buffer whose
 //              column K holds 1: every bias is row K of its weight matrix, so no kernel below has a bias path and db is
 //              a row of dW.
+//              The NEXT step's batch is staged by extra blocks of this step's Adam launch (it depends on nothing the step
+//              computes): a launch of its own only for the first step of a call.
 //   forward    per layer: H_{l+1} = act(H_l W_l), one 32 x 32 output tile per workgroup, the contraction split over its
-//              eight waves and summed through LDS in a fixed order.
-//   loss       sigmoid cross-entropy on the activated outputs, dZ of the last layer.
+//              eight waves and summed through LDS in a fixed order.  The last layer's epilogue is the loss: sigmoid
+//              cross-entropy on the activated outputs and dZ of the last layer, one share of the cost per 32 rows.
 //   backward   per layer, ONE launch: dW_l = H_l^T dZ_l (tiles over [Kp][Np], contraction over the rows) and, for l > 0,
 //              dZ_{l-1} = (dZ_l W_l^T) * act'(H_l) (tiles over [Bp][Kp]).
 //   adam       one thread per parameter of all layers: + beta W where the regulariser names the matrix, TF-1 Adam.
@@ -129,68 +131,67 @@ struct StageParams {
   float *h0;             // [Bp][Kp]
   int32_t B, K, Bp, Kp;
 };
-__global__ __launch_bounds__(256) void dense_stage_kernel(const StageParams p) {
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+__device__ __forceinline__ void stage_block(const StageParams &p, int block) {
+  const int64_t idx = static_cast<int64_t>(block) * 256 + threadIdx.x;
   if (idx >= static_cast<int64_t>(p.Bp) * p.Kp) return;
   const int m = static_cast<int>(idx / p.Kp), k = static_cast<int>(idx % p.Kp);
   float v = 0.f;
   if (m < p.B) v = k < p.K ? p.x[m * p.row_stride + k] : (k == p.K ? 1.0f : 0.f);
   p.h0[idx] = v;
 }
+__global__ __launch_bounds__(256) void dense_stage_kernel(const StageParams p) { stage_block(p, blockIdx.x); }
 
 struct FwdParams {
   const float *h_in;     // [Bp][Kp]
   const float *w;        // [Kp][Np], row K = the bias
   float *h_out;          // [Bp][Np]
   int32_t Kp, Np, B, ones_col, act;   // ones_col: the column of h_out that carries the next layer's 1 (-1: last layer)
+  // last layer only (dz != null; Np == 32, one workgroup per 32 rows): the loss and its gradient in the epilogue
+  const int32_t *labels; // [B] class index: y = one_hot(label, n_out)
+  float *dz;             // [Bp][32] dZ of the last layer, zeros in the padding
+  int32_t n_out;
+  float inv_count;       // 1 / (B n_out)
+  float *ce_part;        // [Bp / 32] this step's cross-entropy shares (already * inv_count)
+  double *ce_acc;        // nullable [Bp / 32]: their running sums over the steps
 };
 __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(const FwdParams p) {
   __shared__ __attribute__((aligned(16))) float red[kWaves * 4 * 64 * 4];
+  __shared__ float ce_wave[4];
   const int nt = p.Np / 32;
   const int m0 = 32 * (blockIdx.x / nt), n0 = 32 * (blockIdx.x % nt);
   f32x4 c;
-  if (!tile_product<true, false>(p.h_in, p.Kp, p.w, p.Np, m0, n0, p.Kp / 32, red, c)) return;
+  const bool fin = tile_product<true, false>(p.h_in, p.Kp, p.w, p.Np, m0, n0, p.Kp / 32, red, c);
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, n = n0 + (lane & 31), half = lane >> 5;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int m = m0 + row_of(4 * w + e, half);
-    float h = act_fn(c[e], p.act);
-    if (n == p.ones_col) h = m < p.B ? 1.0f : 0.f;
-    p.h_out[static_cast<int64_t>(m) * p.Np + n] = h;
-  }
-}
-
-struct LossParams {
-  const float *pred;     // [Bp][Np] activated outputs
-  const int32_t *labels; // [B] class index: y = one_hot(label, n_out)
-  float *dz;             // [Bp][Np]: columns >= n_out and rows >= B stay 0 (never written)
-  int32_t B, Np, n_out, act;
-  float inv_count;       // 1 / (B n_out)
-  float *ce_step;        // this step's cross-entropy mean
-  double *ce_acc;        // nullable: running sum over the steps
-};
-__global__ __launch_bounds__(256) void dense_loss_kernel(const LossParams p) {
   float ce = 0.f;
-  for (int m = threadIdx.x; m < p.B; m += 256) {
-    const int label = p.labels[m];
-    for (int c = 0; c < p.n_out; ++c) {
-      const float z = p.pred[static_cast<int64_t>(m) * p.Np + c];
-      const float y = c == label ? 1.0f : 0.f;
-      const float ez = __expf(-fabsf(z));
-      ce += fmaxf(z, 0.f) - z * y + log1pf(ez);
-      const float sig = z >= 0.f ? 1.0f / (1.0f + ez) : ez / (1.0f + ez);
-      p.dz[static_cast<int64_t>(m) * p.Np + c] = (sig - y) * p.inv_count * dact_from_output(z, p.act);
+  if (fin) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = m0 + row_of(4 * w + e, half);
+      float h = act_fn(c[e], p.act);
+      if (n == p.ones_col) h = m < p.B ? 1.0f : 0.f;
+      p.h_out[static_cast<int64_t>(m) * p.Np + n] = h;
+      if (p.dz) {   // kernel-uniform: sigmoid cross-entropy on the ACTIVATED output h, and dZ = dL/dh * act'(h)
+        float d = 0.f;
+        if (m < p.B && n < p.n_out) {
+          const float y = n == p.labels[m] ? 1.0f : 0.f;
+          const float ez = __expf(-fabsf(h));
+          ce += fmaxf(h, 0.f) - h * y + log1pf(ez);
+          const float sig = h >= 0.f ? 1.0f / (1.0f + ez) : ez / (1.0f + ez);
+          d = (sig - y) * p.inv_count * dact_from_output(h, p.act);
+        }
+        p.dz[static_cast<int64_t>(m) * p.Np + n] = d;
+      }
     }
   }
-  __shared__ float part[4];
+  if (!p.dz) return;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) ce += __shfl_xor(ce, off);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ce;
+  if (fin && lane == 0) ce_wave[w] = ce;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float total = ((part[0] + part[1]) + (part[2] + part[3])) * p.inv_count;
-    *p.ce_step = total;
-    if (p.ce_acc) *p.ce_acc += static_cast<double>(total);
+    const float part = ((ce_wave[0] + ce_wave[1]) + (ce_wave[2] + ce_wave[3])) * p.inv_count;
+    p.ce_part[blockIdx.x] = part;
+    if (p.ce_acc) p.ce_acc[blockIdx.x] += static_cast<double>(part);   // own slot, stream-ordered steps
   }
 }
 
@@ -236,14 +237,23 @@ struct DenseAdamParams {
   float lr_t, beta1, beta2, eps, beta_reg;
   int32_t apply;
   float *gsum;           // apply == 0: the gradient incl. beta W
-  double *reg_acc;       // nullable [gridDim.x]
-  float *reg_part;       // [gridDim.x] (cost_out != null)
-  const float *ce_step;
+  double *reg_acc;       // nullable [adam_blocks]
+  float *reg_part;       // [adam_blocks] (cost_out != null)
+  const float *ce_part;  // [n_row_tiles]
+  int32_t n_row_tiles, adam_blocks;
   float *cost_out;       // nullable: this step's cost, assembled by the last block
   unsigned *done;
+  // the NEXT step's batch is staged by extra blocks of this launch (it depends on nothing this step computes)
+  StageParams next;
+  int32_t n_stage_blocks;
 };
 __global__ __launch_bounds__(256) void dense_adam_kernel(const DenseAdamParams p) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (static_cast<int>(blockIdx.x) < p.n_stage_blocks) {
+    stage_block(p.next, blockIdx.x);
+    return;
+  }
+  const int bid = blockIdx.x - p.n_stage_blocks;
+  const int64_t i = static_cast<int64_t>(bid) * 256 + threadIdx.x;
   float reg = 0.f;
   if (i < p.n_params) {
     const float wv = p.w[i];
@@ -280,26 +290,28 @@ __global__ __launch_bounds__(256) void dense_adam_kernel(const DenseAdamParams p
   __syncthreads();
   if (threadIdx.x == 0) {
     const float block_reg = (wave_reg[0] + wave_reg[1]) + (wave_reg[2] + wave_reg[3]);
-    if (p.reg_acc) p.reg_acc[blockIdx.x] += static_cast<double>(block_reg);
+    if (p.reg_acc) p.reg_acc[bid] += static_cast<double>(block_reg);
     if (p.cost_out) {
-      p.reg_part[blockIdx.x] = block_reg;
+      p.reg_part[bid] = block_reg;
       __threadfence();
       ticket = atomicAdd(p.done, 1u);
     }
   }
   if (!p.cost_out) return;   // kernel-uniform
   __syncthreads();
-  if (ticket == gridDim.x - 1) {   // the last block to finish adds the shares up (fixed order per lane)
+  if (ticket == static_cast<unsigned>(p.adam_blocks) - 1) {   // the last block to finish adds the shares up (fixed order per lane)
     __threadfence();
-    float r = 0.f;
-    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) r += __builtin_nontemporal_load(p.reg_part + b);
+    float r = 0.f, ce = 0.f;
+    for (int b = threadIdx.x; b < p.adam_blocks; b += 256) r += __builtin_nontemporal_load(p.reg_part + b);
+    for (int b = threadIdx.x; b < p.n_row_tiles; b += 256) ce += p.ce_part[b];
+    float t = ce + p.beta_reg * r;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off);
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) wave_reg[threadIdx.x >> 6] = r;
+    if ((threadIdx.x & 63) == 0) wave_reg[threadIdx.x >> 6] = t;
     __syncthreads();
     if (threadIdx.x == 0) {
-      *p.cost_out = *p.ce_step + p.beta_reg * ((wave_reg[0] + wave_reg[1]) + (wave_reg[2] + wave_reg[3]));
+      *p.cost_out = (wave_reg[0] + wave_reg[1]) + (wave_reg[2] + wave_reg[3]);
       *p.done = 0u;
     }
   }
@@ -319,7 +331,8 @@ struct nnv_dense_train_handle {
   float *w, *m, *v, *dw, *gsum;     // [n_params]
   float *h[nnv::kMaxL + 1];         // h[0] = the staged batch, h[l + 1] = layer l's output
   float *dz[nnv::kMaxL];
-  float *reg_part, *ce_step, *cost_scratch;
+  float *reg_part, *ce_part, *cost_scratch;
+  int32_t n_row_tiles;
   unsigned *done;
   double *ce_acc, *reg_acc;
 };
@@ -328,23 +341,35 @@ namespace {
 
 int round_up32(int v) { return (v + 31) / 32 * 32; }
 
-nnv_status dense_fwd_bwd(nnv_dense_train_handle *h, const float *x, int64_t row_stride, const int32_t *labels, bool training_step,
-                         hipStream_t s) {
-  {
-    nnv::StageParams p{x, row_stride, h->h[0], h->B, h->K[0], h->Bp, h->Kp[0]};
-    const int64_t n = static_cast<int64_t>(h->Bp) * h->Kp[0];
-    hipLaunchKernelGGL(nnv::dense_stage_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, p);
-  }
+nnv::StageParams stage_params(const nnv_dense_train_handle *h, const float *x, int64_t row_stride) {
+  return nnv::StageParams{x, row_stride, h->h[0], h->B, h->K[0], h->Bp, h->Kp[0]};
+}
+unsigned stage_blocks(const nnv_dense_train_handle *h) {
+  return static_cast<unsigned>((static_cast<int64_t>(h->Bp) * h->Kp[0] + 255) / 256);
+}
+
+// forward (the loss in the last layer's epilogue) and backward of the batch that is ALREADY staged in h->h[0]
+nnv_status dense_fwd_bwd(nnv_dense_train_handle *h, const int32_t *labels, bool training_step, hipStream_t s) {
   for (int l = 0; l < h->L; ++l) {
-    nnv::FwdParams p{h->h[l], h->w + h->off_w[l], h->h[l + 1], h->Kp[l], h->Np[l], h->B, l + 1 < h->L ? h->N[l] : -1, h->act};
+    const bool last = l + 1 == h->L;
+    nnv::FwdParams p{};
+    p.h_in = h->h[l];
+    p.w = h->w + h->off_w[l];
+    p.h_out = h->h[l + 1];
+    p.Kp = h->Kp[l];
+    p.Np = h->Np[l];
+    p.B = h->B;
+    p.ones_col = last ? -1 : h->N[l];
+    p.act = h->act;
+    if (last) {
+      p.labels = labels;
+      p.dz = h->dz[l];
+      p.n_out = h->n_out;
+      p.inv_count = 1.0f / (static_cast<float>(h->B) * static_cast<float>(h->n_out));
+      p.ce_part = h->ce_part;
+      p.ce_acc = training_step ? h->ce_acc : nullptr;
+    }
     hipLaunchKernelGGL(nnv::dense_fwd_kernel, dim3((h->Bp / 32) * (h->Np[l] / 32)), dim3(nnv::kThreads), 0, s, p);
-  }
-  {
-    const int last = h->L - 1;
-    nnv::LossParams p{h->h[h->L], labels, h->dz[last], h->B, h->Np[last], h->n_out, h->act,
-                      1.0f / (static_cast<float>(h->B) * static_cast<float>(h->n_out)), h->ce_step,
-                      training_step ? h->ce_acc : nullptr};
-    hipLaunchKernelGGL(nnv::dense_loss_kernel, dim3(1), dim3(256), 0, s, p);
   }
   for (int l = h->L - 1; l >= 0; --l) {
     nnv::BwdParams p{h->h[l], h->dz[l], h->w + h->off_w[l], h->dw + h->off_w[l], l > 0 ? h->dz[l - 1] : nullptr,
@@ -355,7 +380,8 @@ nnv_status dense_fwd_bwd(nnv_dense_train_handle *h, const float *x, int64_t row_
   return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 
-nnv_status dense_adam(nnv_dense_train_handle *h, bool apply, float *cost_out, hipStream_t s) {
+// next_x: the NEXT step's rows, staged by extra blocks of the Adam launch (nullptr: none)
+nnv_status dense_adam(nnv_dense_train_handle *h, bool apply, float *cost_out, const float *next_x, int64_t row_stride, hipStream_t s) {
   nnv::DenseAdamParams a{};
   a.w = h->w;
   a.m = h->m;
@@ -378,7 +404,14 @@ nnv_status dense_adam(nnv_dense_train_handle *h, bool apply, float *cost_out, hi
   a.gsum = h->gsum;
   a.reg_acc = apply ? h->reg_acc : nullptr;
   a.reg_part = h->reg_part;
-  a.ce_step = h->ce_step;
+  a.ce_part = h->ce_part;
+  a.n_row_tiles = h->n_row_tiles;
+  a.adam_blocks = h->adam_blocks;
+  a.n_stage_blocks = 0;
+  if (next_x) {
+    a.next = stage_params(h, next_x, row_stride);
+    a.n_stage_blocks = static_cast<int32_t>(stage_blocks(h));
+  }
   a.cost_out = cost_out;
   a.done = h->done;
   if (apply) {
@@ -386,7 +419,7 @@ nnv_status dense_adam(nnv_dense_train_handle *h, bool apply, float *cost_out, hi
     const double t = static_cast<double>(h->step);
     a.lr_t = static_cast<float>(static_cast<double>(h->lr) * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
   }
-  hipLaunchKernelGGL(nnv::dense_adam_kernel, dim3(h->adam_blocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(nnv::dense_adam_kernel, dim3(a.n_stage_blocks + h->adam_blocks), dim3(256), 0, s, a);
   return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 
@@ -436,7 +469,9 @@ int32_t nnv_dense_train_create(const nnv_dense_train_desc *d, nnv_dense_train_ha
   h->adam_blocks = static_cast<int32_t>((h->n_params + 255) / 256);
   int64_t act_floats = static_cast<int64_t>(h->Bp) * h->Kp[0];
   for (int l = 0; l < h->L; ++l) act_floats += 2 * static_cast<int64_t>(h->Bp) * h->Np[l];   // h[l + 1] and dz[l]
-  const int64_t total = 5 * h->n_params + act_floats + h->adam_blocks + 8 + 2 * (1 + static_cast<int64_t>(h->adam_blocks));
+  h->n_row_tiles = h->Bp / 32;
+  const int64_t total = 5 * h->n_params + act_floats + h->adam_blocks + h->n_row_tiles + 8 +
+                        2 * (static_cast<int64_t>(h->n_row_tiles) + h->adam_blocks);
   if (hipMalloc(reinterpret_cast<void **>(&h->dev), total * sizeof(float)) != hipSuccess) {
     delete h;
     return NNV_ERR_OUT_OF_MEMORY;
@@ -453,11 +488,11 @@ int32_t nnv_dense_train_create(const nnv_dense_train_desc *d, nnv_dense_train_ha
     h->dz[l] = q; q += static_cast<int64_t>(h->Bp) * h->Np[l];
   }
   h->reg_part = q; q += h->adam_blocks;
-  h->ce_step = q; q += 1;
+  h->ce_part = q; q += h->n_row_tiles;
   h->cost_scratch = q; q += 1;
   h->done = reinterpret_cast<unsigned *>(q); q += 1;
   q += (q - h->dev) & 1;                                             // doubles: 8-byte aligned
-  h->ce_acc = reinterpret_cast<double *>(q); q += 2;
+  h->ce_acc = reinterpret_cast<double *>(q); q += 2 * static_cast<int64_t>(h->n_row_tiles);
   h->reg_acc = reinterpret_cast<double *>(q); q += 2 * static_cast<int64_t>(h->adam_blocks);
   std::vector<float> host(static_cast<size_t>(h->n_params), 0.f);    // everything else starts as zeros
   for (int l = 0; l < h->L; ++l) {
@@ -494,11 +529,12 @@ int32_t nnv_dense_train_steps(nnv_dense_train_handle *h, const float *x_dev, int
     if (dv != NNV_OK) return dv;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(nnv::dense_stage_kernel, dim3(stage_blocks(h)), dim3(256), 0, s, stage_params(h, x_dev, row_stride));
   for (int t = 0; t < n_steps; ++t) {
-    nnv_status st = dense_fwd_bwd(h, x_dev + static_cast<int64_t>(t) * step_stride, row_stride,
-                                  labels_dev + static_cast<int64_t>(t) * h->B, true, s);
+    nnv_status st = dense_fwd_bwd(h, labels_dev + static_cast<int64_t>(t) * h->B, true, s);
     if (st != NNV_OK) return st;
-    st = dense_adam(h, true, costs_dev ? costs_dev + t : nullptr, s);
+    st = dense_adam(h, true, costs_dev ? costs_dev + t : nullptr,
+                    t + 1 < n_steps ? x_dev + static_cast<int64_t>(t + 1) * step_stride : nullptr, row_stride, s);
     if (st != NNV_OK) return st;
   }
   return NNV_OK;
@@ -511,9 +547,10 @@ int32_t nnv_dense_train_gradients(nnv_dense_train_handle *h, const float *x_dev,
     const nnv_status dv = nnv::check_current_device(h->device);
     if (dv != NNV_OK) return dv;
   }
-  nnv_status st = dense_fwd_bwd(h, x_dev, row_stride, labels_dev, false, nullptr);
+  hipLaunchKernelGGL(nnv::dense_stage_kernel, dim3(stage_blocks(h)), dim3(256), 0, nullptr, stage_params(h, x_dev, row_stride));
+  nnv_status st = dense_fwd_bwd(h, labels_dev, false, nullptr);
   if (st != NNV_OK) return st;
-  st = dense_adam(h, false, h->cost_scratch, nullptr);
+  st = dense_adam(h, false, h->cost_scratch, nullptr, 0, nullptr);
   if (st != NNV_OK) return st;
   if (hipDeviceSynchronize() != hipSuccess) return NNV_ERR_HIP;
   std::vector<float> g(static_cast<size_t>(h->n_params));
@@ -551,12 +588,13 @@ int32_t nnv_dense_train_export(const nnv_dense_train_handle *h, float *const W_h
   if (extra_host)
     for (int64_t i = 0; i < h->n_extra; ++i) extra_host[i] = w[static_cast<size_t>(h->n_matrix + i)];
   if (cost_sum_host) {   // sum of the step costs since the last export, then reset
-    const size_t n = 1 + static_cast<size_t>(h->adam_blocks);   // ce_acc and reg_acc are adjacent
+    const size_t n = static_cast<size_t>(h->n_row_tiles) + static_cast<size_t>(h->adam_blocks);   // ce_acc | reg_acc, adjacent
     std::vector<double> acc(n);
     if (hipMemcpy(acc.data(), h->ce_acc, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return NNV_ERR_HIP;
-    double reg = 0.0;
-    for (size_t i = 1; i < n; ++i) reg += acc[i];
-    *cost_sum_host = acc[0] + static_cast<double>(h->beta_reg) * reg;
+    double ce = 0.0, reg = 0.0;
+    for (size_t i = 0; i < static_cast<size_t>(h->n_row_tiles); ++i) ce += acc[i];
+    for (size_t i = static_cast<size_t>(h->n_row_tiles); i < n; ++i) reg += acc[i];
+    *cost_sum_host = ce + static_cast<double>(h->beta_reg) * reg;
     if (hipMemset(h->ce_acc, 0, n * sizeof(double)) != hipSuccess) return NNV_ERR_HIP;
   }
   return NNV_OK;

@@ -245,7 +245,7 @@ def train_and_evaluate(config: BitwiseDecoderConfig, train_info: np.ndarray, tra
     bs = int(config.batch_size)
     total_batch = int(config.training_size / bs)
     if total_batch > 0 and NativeDenseTrainer.eligible(active_layers(weights, biases)[0], config.n_output):
-        # K8 (csrc/nnv_dense_train.hip): the step as 7 hand-written launches.  The regulariser names h1 and h2 (:444-447);
+        # K8 (csrc/nnv_dense_train.hip): the step as 5 hand-written launches.  The regulariser names h1 and h2 (:444-447);
         # h2 is a variable the network never uses (:388-397): it only decays, as an "extra" of the trainer.
         Ws, Bs = active_layers(weights, biases)
         nt = NativeDenseTrainer(Ws, Bs, "relu", config.learning_rate, config.beta_regularization, bs,

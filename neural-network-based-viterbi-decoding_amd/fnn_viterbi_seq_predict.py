@@ -256,7 +256,7 @@ def _train(config: SequentialDecoderConfig, train_info, train_coded, weights, bi
     bs, win = int(config.batch_size), int(config.window_length)
     total_batch = int(config.total_training_instances / bs)
     if total_batch > 0 and NativeDenseTrainer.eligible([weights[k] for k in _W_KEYS], config.n_output):
-        # K8 (csrc/nnv_dense_train.hip): the step as 13 hand-written launches; window i = stream[2 i : 2 i + win] is
+        # K8 (csrc/nnv_dense_train.hip): the step as 11 hand-written launches; window i = stream[2 i : 2 i + win] is
         # addressed inside the staging kernel (row stride 2), so no [instances, win] matrix exists
         nt = NativeDenseTrainer([weights[k] for k in _W_KEYS], [biases[k] for k in _B_KEYS], "tanh", config.learning_rate,
                                 config.beta_regularization, bs, reg_layers=(0, 1))

@@ -342,7 +342,7 @@ class NativeFNNTrainer:
 
 
 class NativeDenseTrainer:
-    """The training step of the reference's bit-wise and sliding-window decoders as 2 L + 3 hand-written HIP launches
+    """The training step of the reference's bit-wise and sliding-window decoders as 2 L + 1 hand-written HIP launches
     per step (C ABI ``nnv_dense_train_*``, csrc/nnv_dense_train.hip) instead of ~60 PyTorch-autograd kernels: a dense
     network of 1..5 layers with the activation after EVERY layer, mean sigmoid cross-entropy on the activated outputs,
     beta * l2_loss of the layers in ``reg_layers``, TF-1 Adam (src/fnn_viterbi_bitwise.py:388-397,438-452;

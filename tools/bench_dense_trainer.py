@@ -22,7 +22,7 @@ for name, dims, act, bs, steps, stride in (("bitwise", [1036, 30, 2], "relu", 10
     rs = n_in if stride is None else stride
     flat = torch.randn(((steps * bs - 1) * rs + n_in,), device="cuda")
     lab = torch.randint(0, 2, (steps * bs,), device="cuda", dtype=torch.int32)
-    res = {"dims": dims, "batch": bs, "steps": steps, "launches_per_step": 2 * (len(dims) - 1) + 3}
+    res = {"dims": dims, "batch": bs, "steps": steps, "launches_per_step": 2 * (len(dims) - 1) + 1}
     nt = training.NativeDenseTrainer(Ws, Bs, act, 2e-4, 1e-4, bs, reg_layers=(0, 1) if len(dims) > 3 else (0,))
     nt.steps(flat, lab, steps, row_stride=rs, step_stride=bs * rs)
     torch.cuda.synchronize()
