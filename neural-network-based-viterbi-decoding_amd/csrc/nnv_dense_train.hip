@@ -238,11 +238,7 @@ struct DenseAdamParams {
   int32_t apply;
   float *gsum;           // apply == 0: the gradient incl. beta W
   double *reg_acc;       // nullable [adam_blocks]
-  float *reg_part;       // [adam_blocks] (cost_out != null)
-  const float *ce_part;  // [n_row_tiles]
-  int32_t n_row_tiles, adam_blocks;
-  float *cost_out;       // nullable: this step's cost, assembled by the last block
-  unsigned *done;
+  float *reg_part;       // nullable [adam_blocks]: this step's shares (the caller wants this step's cost)
   // the NEXT step's batch is staged by extra blocks of this launch (it depends on nothing this step computes)
   StageParams next;
   int32_t n_stage_blocks;
@@ -283,7 +279,6 @@ __global__ __launch_bounds__(256) void dense_adam_kernel(const DenseAdamParams p
     }
   }
   __shared__ float wave_reg[4];
-  __shared__ unsigned ticket;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) reg += __shfl_xor(reg, off);
   if ((threadIdx.x & 63) == 0) wave_reg[threadIdx.x >> 6] = reg;
@@ -291,30 +286,30 @@ __global__ __launch_bounds__(256) void dense_adam_kernel(const DenseAdamParams p
   if (threadIdx.x == 0) {
     const float block_reg = (wave_reg[0] + wave_reg[1]) + (wave_reg[2] + wave_reg[3]);
     if (p.reg_acc) p.reg_acc[bid] += static_cast<double>(block_reg);
-    if (p.cost_out) {
-      p.reg_part[bid] = block_reg;
-      __threadfence();
-      ticket = atomicAdd(p.done, 1u);
-    }
+    if (p.reg_part) p.reg_part[bid] = block_reg;
   }
-  if (!p.cost_out) return;   // kernel-uniform
-  __syncthreads();
-  if (ticket == static_cast<unsigned>(p.adam_blocks) - 1) {   // the last block to finish adds the shares up (fixed order per lane)
-    __threadfence();
-    float r = 0.f, ce = 0.f;
-    for (int b = threadIdx.x; b < p.adam_blocks; b += 256) r += __builtin_nontemporal_load(p.reg_part + b);
-    for (int b = threadIdx.x; b < p.n_row_tiles; b += 256) ce += p.ce_part[b];
-    float t = ce + p.beta_reg * r;
+}
+
+// A caller that wants THIS step's cost (tests, nnv_dense_train_gradients) pays one more small launch that adds the
+// shares up in a fixed order; a training loop does not (an atomic ticket with a fence in every one of the sliding-window
+// network's 3,584 Adam blocks doubled the step).
+struct CostParams {
+  const float *reg_part, *ce_part;
+  int32_t n_reg, n_ce;
+  float beta_reg;
+  float *cost_out;
+};
+__global__ __launch_bounds__(256) void dense_cost_kernel(const CostParams p) {
+  float r = 0.f, ce = 0.f;
+  for (int b = threadIdx.x; b < p.n_reg; b += 256) r += p.reg_part[b];
+  for (int b = threadIdx.x; b < p.n_ce; b += 256) ce += p.ce_part[b];
+  float t = ce + p.beta_reg * r;
+  __shared__ float wave_sum[4];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) wave_reg[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      *p.cost_out = (wave_reg[0] + wave_reg[1]) + (wave_reg[2] + wave_reg[3]);
-      *p.done = 0u;
-    }
-  }
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) *p.cost_out = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
 }
 
 }  // namespace
@@ -333,7 +328,6 @@ struct nnv_dense_train_handle {
   float *dz[nnv::kMaxL];
   float *reg_part, *ce_part, *cost_scratch;
   int32_t n_row_tiles;
-  unsigned *done;
   double *ce_acc, *reg_acc;
 };
 
@@ -403,23 +397,22 @@ nnv_status dense_adam(nnv_dense_train_handle *h, bool apply, float *cost_out, co
   a.apply = apply ? 1 : 0;
   a.gsum = h->gsum;
   a.reg_acc = apply ? h->reg_acc : nullptr;
-  a.reg_part = h->reg_part;
-  a.ce_part = h->ce_part;
-  a.n_row_tiles = h->n_row_tiles;
-  a.adam_blocks = h->adam_blocks;
+  a.reg_part = cost_out ? h->reg_part : nullptr;
   a.n_stage_blocks = 0;
   if (next_x) {
     a.next = stage_params(h, next_x, row_stride);
     a.n_stage_blocks = static_cast<int32_t>(stage_blocks(h));
   }
-  a.cost_out = cost_out;
-  a.done = h->done;
   if (apply) {
     h->step += 1;   // TF-1: lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t), in double on the host
     const double t = static_cast<double>(h->step);
     a.lr_t = static_cast<float>(static_cast<double>(h->lr) * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
   }
   hipLaunchKernelGGL(nnv::dense_adam_kernel, dim3(a.n_stage_blocks + h->adam_blocks), dim3(256), 0, s, a);
+  if (cost_out) {
+    nnv::CostParams c{h->reg_part, h->ce_part, h->adam_blocks, h->n_row_tiles, h->beta_reg, cost_out};
+    hipLaunchKernelGGL(nnv::dense_cost_kernel, dim3(1), dim3(256), 0, s, c);
+  }
   return hipGetLastError() == hipSuccess ? NNV_OK : NNV_ERR_HIP;
 }
 
@@ -490,7 +483,6 @@ int32_t nnv_dense_train_create(const nnv_dense_train_desc *d, nnv_dense_train_ha
   h->reg_part = q; q += h->adam_blocks;
   h->ce_part = q; q += h->n_row_tiles;
   h->cost_scratch = q; q += 1;
-  h->done = reinterpret_cast<unsigned *>(q); q += 1;
   q += (q - h->dev) & 1;                                             // doubles: 8-byte aligned
   h->ce_acc = reinterpret_cast<double *>(q); q += 2 * static_cast<int64_t>(h->n_row_tiles);
   h->reg_acc = reinterpret_cast<double *>(q); q += 2 * static_cast<int64_t>(h->adam_blocks);
