@@ -434,6 +434,37 @@ def next_row_paths(dev, steps: int):
                        "cost_first_last": [float(cd[0].item()), float(cd[-1].item())]}
         del flat, labd
     out["dense_training_steps_K8"] = dense
+    # SURVEY.md section 8(f) rank 4, the training side: the recurrent decoder's step at its default shape (LSTM(20) over 200
+    # coded symbols + 200 decoder steps, batch 100, src/rnn_viterbi.py:28-92, 277-316), both recurrences in K9
+    # (csrc/nnv_lstm_train.hip), replayed from a HIP graph.  The unrolled PyTorch graph (45 ms per step) is not timed here:
+    # capturing its 16,000 kernels takes longer than this whole leg (tools/bench_lstm_trainer.py has both).
+    from nnviterbi_amd import rnn_viterbi as rv
+    cfr = rv.RNNDecoderConfig()
+    mdl = rv.build_seq2seq_model(cfr, rng=np.random.RandomState(0))
+    Tr, Br = cfr.encoded_length, cfr.batch_size
+    er = torch.randn((Tr, Br), device=dev, generator=g)
+    dr = torch.randint(0, 2, (Tr, Br), device=dev, generator=g).float()
+    tr_ = torch.randn((Tr, Br, 1), device=dev, generator=g)
+    Pr = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in mdl["params"].items()}
+    optr = training.TFAdam(list(Pr.values()), lr=cfr.learning_rate)
+
+    def rstep(e, d, t):
+        loss = ((t - training.lstm_seq2seq_logits_native(Pr, e, d, 1.0)) ** 2).mean()
+        optr.zero_grad(set_to_none=False)
+        loss.backward()
+        optr.step()
+        return loss.detach()
+    runr = training.GraphedStep(rstep, list(Pr.values()), optr, (er, dr, tr_), False)
+    for _ in range(3):
+        runr(er, dr, tr_)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        lr_ = runr(er, dr, tr_)
+    torch.cuda.synchronize(dev)
+    out["recurrent_training_step_K9"] = {"t_enc": Tr, "t_dec": Tr, "batch": Br, "hidden": cfr.encoder_hidden_units,
+                                         "ms_per_step": (time.perf_counter() - t0) / 50 * 1e3,
+                                         "graph_captured": bool(runr.captured), "loss_last": float(lr_)}
     return out
 
 

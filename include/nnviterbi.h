@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NNV_ABI_VERSION 8 /* 8: + nnv_dense_train_* (the bit-wise / sliding-window decoders' training step); 7: + nnv_train_* (the training step as two kernels); prior: 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS; 6: + nnv_wide_set_path / _get_path, nnv_bitwise_set_path / _path_for (no environment switches any more) */
+#define NNV_ABI_VERSION 9 /* 9: + nnv_lstm_seq_forward_f32 / _backward_f32 (the recurrent decoder's back-propagation through time); 8: + nnv_dense_train_* (the bit-wise / sliding-window decoders' training step); 7: + nnv_train_* (the training step as two kernels); prior: 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS; 6: + nnv_wide_set_path / _get_path, nnv_bitwise_set_path / _path_for (no environment switches any more) */
 #define NNV_MAX_LAYERS 4 /* dense layers incl. the output layer */
 #define NNV_MLP_MAX_INPUTS 32     /* nnv_mlp_*: row length n_input = 2 b (block_length <= 16); hidden widths: the first 1-3 of
                                      the reference's (128, 64, 32); other shapes: NNV_ERR_UNSUPPORTED_SHAPE -> nnv_wide_* */
@@ -546,6 +546,28 @@ int32_t nnv_dense_train_gradients(nnv_dense_train_handle *h, const float *x_dev,
  * of the step costs since the last export (reset by the call).  Synchronous. */
 int32_t nnv_dense_train_export(const nnv_dense_train_handle *h, float *const W_host[5], float *const b_host[5], float *extra_host,
                                double *cost_sum_host);
+
+/* ------------------------------------------------------------------------
+ * K9: the recurrent half of the recurrent decoder's training step -- one tf.contrib.rnn.LSTMCell unrolled over time by
+ * tf.nn.dynamic_rnn (src/rnn_viterbi.py:277-299; trained on the mean squared error by AdamOptimizer, :310-316), forward
+ * with everything back-propagation needs kept, and backward.  One launch per LSTM and direction with every time step
+ * inside (PyTorch autograd: ~40 kernels per cell, 400 cells per step).  The input projection, the output projection,
+ * the loss, dW_h = sum_t m_{t-1}^T dz_t (one matrix product) and Adam stay with the caller.  All arrays are
+ * [time][feature][batch] fp32 (batch contiguous); gate order i, j, f, o (BasicLSTMCell); hidden must be 20, the
+ * reference's encoder_hidden_units (src/rnn_viterbi.py:36), other sizes: NNV_ERR_UNSUPPORTED_SHAPE.  Asynchronous.
+ *  zx     [T][4H][B]  x_t kernel[0] + bias          wh  [H][4H]  kernel[1:]          c0, m0  [H][B]
+ *  gates  [T][4H][B]  out: sigmoid(i), tanh(j), sigmoid(f + forget_bias), sigmoid(o)
+ *  c_all, m_all [T][H][B] out: the cell and the output of every step (m_all[T-1], c_all[T-1]: the final state)
+ * ------------------------------------------------------------------------ */
+int32_t nnv_lstm_seq_forward_f32(const float *zx_dev, const float *wh_dev, const float *c0_dev, const float *m0_dev,
+                                 int32_t n_steps, int32_t batch, int32_t hidden, float forget_bias, float *gates_dev,
+                                 float *c_all_dev, float *m_all_dev, void *stream);
+/*  dm_all [T][H][B] gradient w.r.t. every m_t as an output; dcT, dmT [H][B] w.r.t. the final state (the decoder's
+ *  initial state is the encoder's final state, src/rnn_viterbi.py:291-296).  Out: dz [T][4H][B] w.r.t. the gate
+ *  pre-activations (= w.r.t. zx), dc0, dm0 [H][B] w.r.t. the initial state. */
+int32_t nnv_lstm_seq_backward_f32(const float *dm_all_dev, const float *dcT_dev, const float *dmT_dev, const float *gates_dev,
+                                  const float *c_all_dev, const float *c0_dev, const float *wh_dev, int32_t n_steps,
+                                  int32_t batch, int32_t hidden, float *dz_dev, float *dc0_dev, float *dm0_dev, void *stream);
 
 /*
  * Timing helper used by bench.py: launches nnv_mlp_decode_f32 `iters` times

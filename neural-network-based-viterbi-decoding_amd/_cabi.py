@@ -15,7 +15,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("NNV_LIB") or os.path.join(_PKG_DIR, "libnnviterbi_hip.so")
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 
-NNV_ABI_VERSION = 8
+NNV_ABI_VERSION = 9
 NNV_MAX_LAYERS = 4
 NNV_OK = 0
 NNV_CODE_57 = 0
@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = (
     "nnv_train_create", "nnv_train_free", "nnv_train_steps", "nnv_train_gradients", "nnv_train_export",
     "nnv_dense_train_create", "nnv_dense_train_free", "nnv_dense_train_steps", "nnv_dense_train_gradients",
     "nnv_dense_train_export",
+    "nnv_lstm_seq_forward_f32", "nnv_lstm_seq_backward_f32",
     "nnv_seq2seq_prepack", "nnv_seq2seq_free", "nnv_seq2seq_forward_f32",
     "nnv_bitwise_prepack", "nnv_bitwise_prepack_ex", "nnv_bitwise_free", "nnv_bitwise_decode_f32",
 )
@@ -258,6 +259,10 @@ def load_library() -> ctypes.CDLL:
     lib.nnv_dense_train_gradients.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
     lib.nnv_dense_train_export.restype = c.c_int32
     lib.nnv_dense_train_export.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.nnv_lstm_seq_forward_f32.restype = c.c_int32
+    lib.nnv_lstm_seq_forward_f32.argtypes = [c.c_void_p] * 4 + [c.c_int32] * 3 + [c.c_float] + [c.c_void_p] * 4
+    lib.nnv_lstm_seq_backward_f32.restype = c.c_int32
+    lib.nnv_lstm_seq_backward_f32.argtypes = [c.c_void_p] * 7 + [c.c_int32] * 3 + [c.c_void_p] * 4
     if lib.nnv_abi_version() != NNV_ABI_VERSION:
         raise NNViterbiError(
             f"ABI mismatch: library {lib.nnv_abi_version()} != binding {NNV_ABI_VERSION}")

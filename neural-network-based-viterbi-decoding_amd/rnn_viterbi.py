@@ -259,8 +259,12 @@ def train_seq2seq(config: RNNDecoderConfig, train_info: np.ndarray, train_encode
     loss_history = []
     forget_bias = float(model.get("forget_bias", 1.0))
 
+    from .training import lstm_native_eligible, lstm_seq2seq_logits_native
+    # K9 (csrc/nnv_lstm_train.hip): each recurrence one launch forward and one backward instead of ~40 kernels per cell
+    forward = lstm_seq2seq_logits_native if (dev.type == "cuda" and lstm_native_eligible(P)) else _torch_forward
+
     def step(enc, dec, tgt):
-        loss = ((tgt - _torch_forward(P, enc, dec, forget_bias)) ** 2).mean()
+        loss = ((tgt - forward(P, enc, dec, forget_bias)) ** 2).mean()
         opt.zero_grad(set_to_none=False)
         loss.backward()
         opt.step()

@@ -462,6 +462,72 @@ class NativeDenseTrainer:
         return out + (float(csum.value),) if want_cost_sum else out
 
 
+class _LSTMSeqFn(torch.autograd.Function):
+    """One tf.contrib.rnn.LSTMCell unrolled over time (src/rnn_viterbi.py:277-299) as ONE HIP launch forward and one
+    backward (K9, csrc/nnv_lstm_train.hip); layouts [T, feature, B].  Inputs: zx [T, 4H, B] = x_t kernel[0] + bias,
+    wh [H, 4H] = kernel[1:], c0, m0 [H, B].  Outputs: m_all [T, H, B], cT, mT [H, B]."""
+
+    @staticmethod
+    def forward(ctx, zx, wh, c0, m0, forget_bias):
+        import ctypes
+        from . import _cabi
+        lib = _cabi.load_library()
+        zx, wh, c0, m0 = zx.contiguous(), wh.contiguous(), c0.contiguous(), m0.contiguous()
+        T, H4, B = zx.shape
+        H = H4 // 4
+        gates = torch.empty_like(zx)
+        c_all = torch.empty((T, H, B), dtype=torch.float32, device=zx.device)
+        m_all = torch.empty_like(c_all)
+        st = lib.nnv_lstm_seq_forward_f32(zx.data_ptr(), wh.data_ptr(), c0.data_ptr(), m0.data_ptr(), T, B, H, float(forget_bias),
+                                          gates.data_ptr(), c_all.data_ptr(), m_all.data_ptr(),
+                                          ctypes.c_void_p(torch.cuda.current_stream(zx.device).cuda_stream))
+        _cabi.check(st, "nnv_lstm_seq_forward_f32")
+        ctx.save_for_backward(wh, c0, m0, gates, c_all, m_all)
+        return m_all, c_all[T - 1].clone(), m_all[T - 1].clone()
+
+    @staticmethod
+    def backward(ctx, dm_all, dcT, dmT):
+        import ctypes
+        from . import _cabi
+        lib = _cabi.load_library()
+        wh, c0, m0, gates, c_all, m_all = ctx.saved_tensors
+        T, H, B = c_all.shape
+        dm_all = torch.zeros_like(c_all) if dm_all is None else dm_all.contiguous()
+        dcT = torch.zeros_like(c0) if dcT is None else dcT.contiguous()
+        dmT = torch.zeros_like(c0) if dmT is None else dmT.contiguous()
+        dz = torch.empty_like(gates)
+        dc0, dm0 = torch.empty_like(c0), torch.empty_like(c0)
+        st = lib.nnv_lstm_seq_backward_f32(dm_all.data_ptr(), dcT.data_ptr(), dmT.data_ptr(), gates.data_ptr(), c_all.data_ptr(),
+                                           c0.data_ptr(), wh.data_ptr(), T, B, H, dz.data_ptr(), dc0.data_ptr(), dm0.data_ptr(),
+                                           ctypes.c_void_p(torch.cuda.current_stream(dz.device).cuda_stream))
+        _cabi.check(st, "nnv_lstm_seq_backward_f32")
+        # dW_h = sum over t of m_{t-1}^T dz_t: ONE matrix product over all (t, row) pairs
+        m_prev = torch.cat([m0[None], m_all[:-1]], dim=0)                       # [T, H, B]
+        dwh = torch.einsum("thb,tgb->hg", m_prev, dz)
+        return dz, dwh, dc0, dm0, None
+
+
+def lstm_seq2seq_logits_native(P, enc, dec, forget_bias: float):
+    """The recurrent decoder's graph (src/rnn_viterbi.py:277-305) with both recurrences in K9: time-major [T, B] inputs,
+    logits [T_dec, B, 1] -- what rnn_viterbi._torch_forward computes cell by cell."""
+    H = P["enc_bias"].shape[0] // 4
+    B = enc.shape[1]
+    zeros = enc.new_zeros((H, B))
+
+    def zx_of(x, kernel, bias):                      # [T, B] -> [T, 4H, B]
+        return x[:, None, :] * kernel[0][None, :, None] + bias[None, :, None]
+
+    _, cT, mT = _LSTMSeqFn.apply(zx_of(enc, P["enc_kernel"], P["enc_bias"]), P["enc_kernel"][1:], zeros, zeros, forget_bias)
+    m_dec, _, _ = _LSTMSeqFn.apply(zx_of(dec, P["dec_kernel"], P["dec_bias"]), P["dec_kernel"][1:], cT, mT, forget_bias)
+    logits = torch.einsum("thb,h->tb", m_dec, P["proj_w"].reshape(H)) + P["proj_b"]
+    return logits[:, :, None]
+
+
+def lstm_native_eligible(P) -> bool:
+    return (torch.cuda.is_available() and os.environ.get("NNV_TRAINER") != "autograd"
+            and P["enc_bias"].shape[0] == 80 and P["dec_bias"].shape[0] == 80)
+
+
 def train_network(config, training_set: np.ndarray, training_labels: np.ndarray,
                   weights: Dict[str, np.ndarray], biases: Dict[str, np.ndarray],
                   use_dropout: bool = False, keep_prob: float = 0.5,
