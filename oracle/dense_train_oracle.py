@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY (see oracle/README or DESIGN.md section 2): float64 restatement of the training step the
+"""TEST INFRASTRUCTURE ONLY: float64 restatement of the training step the
 reference's bit-wise and sliding-window decoders share.  Only tests/ may import this.
 
     pred = act(... act(act(x W1 + b1) W2 + b2) ...)          the activation follows EVERY layer, the output layer included
