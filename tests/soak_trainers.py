@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Random-shape soak of the training kernels against their float64 restatements (not a test: a longer run of what
+tests/test_dense_trainer.py and tests/test_trainer.py do on a few fixed shapes).  K8: 1-5 layers, widths 1..70 around
+the 32-tile edges, 1..32 outputs, batches 1..140, both activations, strided rows, extras; K7: class counts 2..256, batches of
+1..6 workgroups, dropout masks.  tests/test_gpu_trainer_soak.py runs 150 cases of it.
+Usage: python tests/soak_trainers.py [n_cases] [seed]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nnviterbi_amd  # noqa: F401
+from nnviterbi_amd import training
+from oracle import dense_train_oracle as DO, train_oracle as TO
+
+def run(n_cases: int = 200, seed: int = 0, verbose: bool = True):
+    """Returns (worst differences, list of cases beyond the bounds)."""
+    rng = np.random.RandomState(seed)
+    flagged = []
+    edge = [1, 2, 3, 7, 30, 31, 32, 33, 63, 64, 65, 70]
+    worst = {"k8_grad": 0.0, "k8_w": 0.0, "k8_cost": 0.0, "k7_grad": 0.0, "k7_w": 0.0}
+    t0 = time.time()
+    for case in range(n_cases):
+        L = rng.randint(1, 6)
+        dims = [int(rng.choice(edge + [100, 200]))] + [int(rng.choice(edge)) for _ in range(L - 1)] + [int(rng.randint(1, 33))]
+        kind = "tanh" if rng.rand() < 0.5 else "relu"
+        batch = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 127, 140]))
+        reg = tuple(l for l in range(L) if rng.rand() < 0.5)
+        extra = [rng.randn(int(rng.randint(1, 9)), int(rng.randint(1, 9))).astype(np.float32)] if rng.rand() < 0.3 else None
+        stride = dims[0] if rng.rand() < 0.5 else int(rng.randint(1, dims[0] + 3))
+        Ws = [(rng.randn(dims[i], dims[i + 1]) * np.sqrt(1.5 / dims[i])).astype(np.float32) for i in range(L)]
+        bs = [(rng.randn(dims[i + 1]) * 0.2).astype(np.float32) for i in range(L)]
+        n_steps = 2
+        flat = rng.randn((n_steps * batch - 1) * stride + dims[0] + 3).astype(np.float32)
+        lab = rng.randint(0, dims[-1], n_steps * batch).astype(np.int32)
+        rows = np.stack([flat[m * stride:m * stride + dims[0]] for m in range(n_steps * batch)])
+        y = np.eye(dims[-1])[lab]
+        beta, lr = 10 ** rng.uniform(-4, -1), 10 ** rng.uniform(-4, -2)
+        ref = DO.Trainer(Ws, bs, kind, lr, beta, reg, extra)
+        nt = training.NativeDenseTrainer(Ws, bs, kind, lr, beta, batch, reg_layers=reg, extra=extra)
+        xd, ld = torch.tensor(flat, device="cuda"), torch.tensor(lab, device="cuda")
+        cost, gW, gb, ge = nt.gradients(xd, ld, row_stride=stride)
+        rcost, dW, db, de = ref.gradients(rows[:batch], y[:batch])
+        g_err = max(np.abs(a.astype(np.float64) - b).max() for a, b in zip(gW + gb + ge, dW + db + de))
+        costs = nt.steps(xd, ld, n_steps, row_stride=stride, step_stride=batch * stride, want_costs=True).cpu().numpy()
+        rc = [ref.step(rows[t * batch:(t + 1) * batch], y[t * batch:(t + 1) * batch]) for t in range(n_steps)]
+        w, b_, e = nt.export()
+        w_err = max(np.abs(a.astype(np.float64) - r).max() for a, r in zip(w + b_ + e, ref.Ws + ref.bs + ref.extra))
+        c_err = max(abs(cost - rcost), np.abs(costs - np.array(rc)).max())
+        nt.close()
+        worst["k8_grad"], worst["k8_w"], worst["k8_cost"] = max(worst["k8_grad"], g_err), max(worst["k8_w"], w_err), max(worst["k8_cost"], c_err)
+        # relu kinks make a gradient discontinuous: a pre-activation within rounding of 0 may flip -- report, do not hide
+        # weights: Adam divides by sqrt(v) + 1e-8, so a gradient component of rounding size moves its weight by up to lr
+        # whatever its sign -- the bound on the weights is a fraction of lr, not of the gradient tolerance
+        if g_err > 2e-6 or w_err > max(1e-5, 0.05 * lr) or c_err > 5e-6:
+            flagged.append(f"K8 case {case}: dims {dims} {kind} batch {batch} reg {reg} stride {stride} lr {lr:.1e}: grad {g_err:.2e} w {w_err:.2e} cost {c_err:.2e}")
+            print(flagged[-1], flush=True)
+        if case % 4 == 0:   # K7
+            n_cls = int(rng.choice([2, 31, 32, 33, 64, 100, 128, 200, 256]))
+            n_in = int(rng.randint(2, 33))
+            bk = 32 * int(rng.randint(1, 7))
+            drop = rng.rand() < 0.4
+            dd = [n_in, 128, 64, 32, n_cls]
+            wk = {k: (rng.randn(dd[i], dd[i + 1]) * np.sqrt(2.0 / dd[i])).astype(np.float32) for i, k in enumerate(("h1", "h2", "h3", "out"))}
+            bk_ = {k: (rng.randn(dd[i + 1]) * 0.1).astype(np.float32) for i, k in enumerate(("b1", "b2", "b3", "out"))}
+            x = rng.randn(2 * bk, n_in).astype(np.float32)
+            lb = rng.randint(0, n_cls, 2 * bk).astype(np.int32)
+            yy = np.eye(n_cls)[lb]
+            masks = [[(rng.rand(bk, wdt) < 0.5).astype(np.float32) for wdt in (128, 64, 32)] for _ in range(2)] if drop else None
+            r7 = TO.Trainer(wk, bk_, 1e-3, 1e-3, keep_prob=0.5 if drop else 1.0)
+            n7 = training.NativeFNNTrainer(wk, bk_, 1e-3, 1e-3, bk, use_dropout=drop, keep_prob=0.5)
+            xd, ld = torch.tensor(x, device="cuda"), torch.tensor(lb, device="cuda")
+            md = [torch.tensor(np.concatenate([masks[t][l] for t in range(2)]), device="cuda") for l in range(3)] if drop else None
+            c7, g7 = n7.gradients(xd[:bk], ld[:bk], [m[:bk].contiguous() for m in md] if drop else None)
+            rc7, dW7, db7 = r7.gradients(x[:bk], yy[:bk], masks[0] if drop else None)
+            g_err = max(np.abs(a.astype(np.float64) - b).max() for a, b in zip(g7, dW7 + db7))
+            n7.steps(xd, ld, 2, masks=md)
+            for t in range(2):
+                r7.step(x[t * bk:(t + 1) * bk], yy[t * bk:(t + 1) * bk], masks[t] if drop else None)
+            gw, gb2 = n7.export()
+            w_err = max(np.abs(gw[k].astype(np.float64) - r).max() for k, r in zip(("h1", "h2", "h3", "out"), r7.Ws))
+            n7.close()
+            worst["k7_grad"], worst["k7_w"] = max(worst["k7_grad"], g_err), max(worst["k7_w"], w_err)
+            if g_err > 2e-6 or w_err > 5e-5:     # lr 1e-3: see above
+                flagged.append(f"K7 case {case}: n_in {n_in} classes {n_cls} batch {bk} dropout {drop}: grad {g_err:.2e} w {w_err:.2e}")
+                print(flagged[-1], flush=True)
+        if verbose and case % 50 == 49:
+            print(f"{case + 1} cases, {time.time() - t0:.0f} s, worst so far {worst}", flush=True)
+    if verbose:
+        print(f"done: {n_cases} K8 cases, {(n_cases + 3) // 4} K7 cases, worst absolute differences {worst}")
+    return worst, flagged
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
