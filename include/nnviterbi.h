@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NNV_ABI_VERSION 9 /* 9: + nnv_lstm_seq_forward_f32 / _backward_f32 (the recurrent decoder's back-propagation through time); 8: + nnv_dense_train_* (the bit-wise / sliding-window decoders' training step); 7: + nnv_train_* (the training step as two kernels); prior: 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS; 6: + nnv_wide_set_path / _get_path, nnv_bitwise_set_path / _path_for (no environment switches any more) */
+#define NNV_ABI_VERSION 10 /* 10: + nnv_mlp_set_path / nnv_mlp_path_for (K1w, the decode kernel for short inputs); 9: + nnv_lstm_seq_forward_f32 / _backward_f32 (the recurrent decoder's back-propagation through time); 8: + nnv_dense_train_* (the bit-wise / sliding-window decoders' training step); 7: + nnv_train_* (the training step as two kernels); prior: 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS; 6: + nnv_wide_set_path / _get_path, nnv_bitwise_set_path / _path_for (no environment switches any more) */
 #define NNV_MAX_LAYERS 4 /* dense layers incl. the output layer */
 #define NNV_MLP_MAX_INPUTS 32     /* nnv_mlp_*: row length n_input = 2 b (block_length <= 16); hidden widths: the first 1-3 of
                                      the reference's (128, 64, 32); other shapes: NNV_ERR_UNSUPPORTED_SHAPE -> nnv_wide_* */
@@ -177,6 +177,27 @@ int32_t nnv_mlp_decode_host_f32(nnv_mlp_handle *h, const float *x_host,
                                 const int32_t *labels_host, int32_t *cls32_host,
                                 int64_t *cls64_host, uint64_t *counters_host,
                                 int64_t chunk_rows, int32_t n_threads);
+
+/*
+ * Which kernel nnv_mlp_decode_f32 launches.  K1 (PERSISTENT) stages the packed network into LDS once per workgroup
+ * and walks 32-row tiles wave by wave: the throughput shape.  K1w (SPLIT) gives every 32-row tile a workgroup of four
+ * waves that share each layer's tiles and read the weights from L2: the latency shape for short inputs (BASELINE
+ * configs[0], 2,000 rows: the call the reference makes as predictions_tensor.eval(feed_dict={x: test_set}),
+ * src/fnn_viterbi.py:606-610, with a small test_set).  Same packed network, same arithmetic, same decision rule: the
+ * two return the same classes bit for bit.  AUTO (the default) takes K1w up to 1,024 tiles for fp32 networks with the
+ * reference's hidden widths (128, 64, 32) and K1 otherwise; nnv_mlp_decode_binned_f32 and nnv_mlp_forward_f32 always
+ * run K1.  nnv_mlp_set_path(SPLIT) on a network K1w does not take: NNV_ERR_UNSUPPORTED_SHAPE, nothing changes.  Not to
+ * be called while another thread decodes with the same handle.
+ */
+typedef enum nnv_mlp_path {
+  NNV_MLP_PATH_AUTO = 0,
+  NNV_MLP_PATH_PERSISTENT = 1, /* K1  */
+  NNV_MLP_PATH_SPLIT = 2       /* K1w */
+} nnv_mlp_path;
+int32_t nnv_mlp_set_path(nnv_mlp_handle *h, int32_t path);
+/* The kernel a decode of n_rows rows runs on this handle: NNV_MLP_PATH_PERSISTENT or NNV_MLP_PATH_SPLIT (negative
+ * nnv_status for bad arguments). */
+int32_t nnv_mlp_path_for(const nnv_mlp_handle *h, int64_t n_rows);
 
 /*
  * The same launch with error counters kept PER SNR BIN, for mixed-SNR sweeps

@@ -15,7 +15,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("NNV_LIB") or os.path.join(_PKG_DIR, "libnnviterbi_hip.so")
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 
-NNV_ABI_VERSION = 9
+NNV_ABI_VERSION = 10
 NNV_MAX_LAYERS = 4
 NNV_OK = 0
 NNV_CODE_57 = 0
@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = (
     "nnv_dense_train_create", "nnv_dense_train_free", "nnv_dense_train_steps", "nnv_dense_train_gradients",
     "nnv_dense_train_export",
     "nnv_lstm_seq_forward_f32", "nnv_lstm_seq_backward_f32",
+    "nnv_mlp_set_path", "nnv_mlp_path_for",
     "nnv_seq2seq_prepack", "nnv_seq2seq_free", "nnv_seq2seq_forward_f32",
     "nnv_bitwise_prepack", "nnv_bitwise_prepack_ex", "nnv_bitwise_free", "nnv_bitwise_decode_f32",
 )
@@ -59,6 +60,7 @@ class WideDesc(ctypes.Structure):
 
 
 NNV_ACTIVATION = {"tanh": 0, "relu": 1}
+NNV_MLP_PATH = {"auto": 0, "persistent": 1, "split": 2}
 NNV_WIDE_PATH = {"auto": 0, "fused": 1, "layered": 2}                 # nnv_wide_path
 NNV_BITWISE_PATH = {"auto": 0, "tiled": 1, "stream": 2, "single": 3}  # nnv_bitwise_path
 
@@ -263,6 +265,10 @@ def load_library() -> ctypes.CDLL:
     lib.nnv_lstm_seq_forward_f32.argtypes = [c.c_void_p] * 4 + [c.c_int32] * 3 + [c.c_float] + [c.c_void_p] * 4
     lib.nnv_lstm_seq_backward_f32.restype = c.c_int32
     lib.nnv_lstm_seq_backward_f32.argtypes = [c.c_void_p] * 7 + [c.c_int32] * 3 + [c.c_void_p] * 4
+    lib.nnv_mlp_set_path.restype = c.c_int32
+    lib.nnv_mlp_set_path.argtypes = [c.c_void_p, c.c_int32]
+    lib.nnv_mlp_path_for.restype = c.c_int32
+    lib.nnv_mlp_path_for.argtypes = [c.c_void_p, c.c_int64]
     if lib.nnv_abi_version() != NNV_ABI_VERSION:
         raise NNViterbiError(
             f"ABI mismatch: library {lib.nnv_abi_version()} != binding {NNV_ABI_VERSION}")

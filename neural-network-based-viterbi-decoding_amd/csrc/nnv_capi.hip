@@ -225,6 +225,12 @@ nnv_status make_params(const nnv_mlp_handle *h, const float *x_dev, int64_t n_ro
   return NNV_OK;
 }
 
+// K1w (nnv_mlp_split.hip) or K1: pinned by nnv_mlp_set_path, else K1w for short inputs of the shapes it takes
+bool use_split(const nnv_mlp_handle *h, int64_t n_tiles) {
+  if (h->path == NNV_MLP_PATH_PERSISTENT || !nnv::split_supported(h->shape)) return false;
+  return h->path == NNV_MLP_PATH_SPLIT || n_tiles <= nnv::kSplitAutoMaxTiles;
+}
+
 }  // namespace
 
 namespace nnv {
@@ -299,6 +305,7 @@ int32_t nnv_mlp_prepack_ex(const nnv_mlp_desc *net, int32_t precision, nnv_mlp_h
   h->lds_limit = kLdsLimitBytes;
   h->wpack_dev = nullptr;
   h->host_ctx = nullptr;
+  h->path = NNV_MLP_PATH_AUTO;
   if (hipMalloc(reinterpret_cast<void **>(&h->wpack_dev), packed.size() * sizeof(float)) != hipSuccess) {
     delete h;
     return NNV_ERR_OUT_OF_MEMORY;
@@ -351,7 +358,20 @@ int32_t nnv_mlp_decode_f32(const nnv_mlp_handle *h, const float *x_dev, int64_t 
   p.cls64 = cls64_dev;
   p.bits = bits_dev;
   p.counters = reinterpret_cast<unsigned long long *>(counters_dev);
+  if (use_split(h, p.n_tiles)) return nnv::split_launch(h->shape, p, static_cast<hipStream_t>(stream));
   return nnv::decode_launch(h->shape, p, plan, false, h->device, static_cast<hipStream_t>(stream));
+}
+
+int32_t nnv_mlp_set_path(nnv_mlp_handle *h, int32_t path) {
+  if (!h || (path != NNV_MLP_PATH_AUTO && path != NNV_MLP_PATH_PERSISTENT && path != NNV_MLP_PATH_SPLIT)) return NNV_ERR_INVALID_ARGUMENT;
+  if (path == NNV_MLP_PATH_SPLIT && !nnv::split_supported(h->shape)) return NNV_ERR_UNSUPPORTED_SHAPE;
+  h->path = path;
+  return NNV_OK;
+}
+
+int32_t nnv_mlp_path_for(const nnv_mlp_handle *h, int64_t n_rows) {
+  if (!h || n_rows < 0) return -NNV_ERR_INVALID_ARGUMENT;
+  return use_split(h, (n_rows + nnv::kRowsPerTile - 1) / nnv::kRowsPerTile) ? NNV_MLP_PATH_SPLIT : NNV_MLP_PATH_PERSISTENT;
 }
 
 int32_t nnv_mlp_decode_binned_f32(const nnv_mlp_handle *h, const float *x_dev, int64_t n_rows,

@@ -367,6 +367,15 @@ struct HostPathCtx;                           // nnv_host_path.hip: persistent p
 void host_path_release(nnv_mlp_handle *h);    // frees it (nnv_mlp_free)
 }  // namespace nnv
 
+namespace nnv {
+// nnv_mlp_split.hip: K1w, the fused decode for short inputs (a workgroup of four waves per 32-row tile, weights from L2)
+bool split_supported(const PackedShape &s);
+nnv_status split_launch(const PackedShape &s, const DecodeParams &p, hipStream_t stream);
+// NNV_MLP_PATH_AUTO takes K1w up to this many 32-row tiles (where K1's persistent workgroups would each walk one tile
+// behind a full staging copy of the network); measured crossover: see DESIGN.md section 5
+constexpr int64_t kSplitAutoMaxTiles = 1024;
+}  // namespace nnv
+
 struct nnv_mlp_handle {
   nnv::PackedShape shape;
   int32_t dims[NNV_MAX_LAYERS + 1];
@@ -378,4 +387,5 @@ struct nnv_mlp_handle {
   int threads;  // workgroup size of the decode kernels, picked at prepack
   int vgprs;    // of the decode instantiation the benchmark call shape uses (lean if eligible)
   nnv::HostPathCtx *host_ctx;  // created by the first nnv_mlp_decode_host_f32 call on this handle
+  int32_t path;                // nnv_mlp_path: AUTO unless nnv_mlp_set_path pinned it
 };

@@ -274,6 +274,18 @@ class PackedMLP:
         _cabi.check(st, "nnv_mlp_decode_f32_timed")
         return float(ms.value)
 
+    def set_path(self, path: str) -> None:
+        """Pin ``decode`` to one kernel: "persistent" (K1: the network staged into LDS once per workgroup, tiles walked
+        wave by wave -- the throughput shape), "split" (K1w: a workgroup of four waves per 32-row tile, weights from L2
+        -- the latency shape for short inputs; fp32 networks with the reference's hidden widths only, else raises) or
+        "auto" (K1w up to 1,024 tiles where it applies, the default).  The two return the same classes bit for bit."""
+        _cabi.check(self._lib.nnv_mlp_set_path(self._handle, _cabi.NNV_MLP_PATH[path]), "nnv_mlp_set_path")
+
+    def path_for(self, n_rows: int) -> str:
+        """The kernel a ``decode`` of ``n_rows`` rows runs: "persistent" or "split"."""
+        v = int(self._lib.nnv_mlp_path_for(self._handle, int(n_rows)))
+        return {1: "persistent", 2: "split"}[v]
+
     def launch_info(self, n_rows: int) -> Dict[str, int]:
         info = (ctypes.c_int32 * 10)()
         with torch.cuda.device(self.device):

@@ -42,6 +42,21 @@ def _check_ff(cls, act, x, Ws, bs, activation="tanh"):
         assert O.top2_margin(o64)[bad].max() < TOL, "class differs on a row that is not a near-tie"
 
 
+def _pinned_paths_agree(net, xd, labels_d, b, r):
+    """K1 (persistent) and, where the network allows it, K1w (split) pinned explicitly: the same classes, bits and
+    counters as the automatic choice, bit for bit."""
+    from nnviterbi_amd import _cabi
+    for path in ("persistent", "split"):
+        try:
+            net.set_path(path)
+        except _cabi.NNViterbiError:
+            continue                      # K1w does not take this network (precision / hidden widths)
+        q = net.decode(xd, labels=labels_d, tile_bits=b, want_cls64=True, want_bits=True)
+        for k in ("cls32", "cls64", "bits", "counters"):
+            assert torch.equal(q[k], r[k]), (path, k)
+    net.set_path("auto")
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("seed", range(12 * SCALE))
 def test_fused_decoder_random_shapes(cuda_device, seed, precision):
@@ -64,6 +79,7 @@ def test_fused_decoder_random_shapes(cuda_device, seed, precision):
     assert np.array_equal(r["cls64"].cpu().numpy(), cls.astype(np.int64))
     assert np.array_equal(r["bits"].cpu().numpy(), O.class_to_bits(cls, b))
     assert np.array_equal(r["counters"].cpu().numpy(), O.error_counters(cls, labels, b))
+    _pinned_paths_agree(net, xd, torch.from_numpy(labels).cuda(), b, r)
     # the classes+counters call shape (lean instantiation where the shape allows it) and the host-array
     # entry (pinned ring, random chunking / thread count) must give the very same classes and counters
     lean = net.decode(xd, labels=torch.from_numpy(labels).cuda(), tile_bits=b)
@@ -103,6 +119,7 @@ def test_fused_decoder_random_shapes_long_rows(cuda_device, seed, precision):
     assert np.array_equal(r["cls64"].cpu().numpy(), cls.astype(np.int64))
     assert np.array_equal(r["bits"].cpu().numpy(), O.class_to_bits(cls, b))
     assert np.array_equal(r["counters"].cpu().numpy(), O.error_counters(cls, labels, b))
+    _pinned_paths_agree(net, xd, torch.from_numpy(labels).cuda(), b, r)
     lean = net.decode(xd, labels=torch.from_numpy(labels).cuda(), tile_bits=b)
     assert np.array_equal(lean["cls32"].cpu().numpy(), cls) and torch.equal(lean["counters"], r["counters"])
     net.close()
