@@ -6,7 +6,7 @@
 //   c_t = sigmoid(f + forget_bias) c_{t-1} + sigmoid(i) tanh(j);  m_t = sigmoid(o) tanh(c_t)
 //
 // PyTorch autograd unrolls 4 L = 400 cells into ~16,000 tiny kernels per training step (45 ms replayed from a HIP graph:
-// the reference's default run takes 4.5 minutes).  Here the RECURRENCE is one launch per LSTM and direction, every
+// the reference's default run takes 4.5 minutes; K9: 4.7 ms).  Here the RECURRENCE is one launch per LSTM and direction, every
 // time step inside it; what is not recurrent stays a handful of PyTorch kernels around it:
 //   before:  zx[t] = x_t kernel[0] + bias for all t at once (one broadcast; its gradient is autograd's)
 //   K9 fwd:  one lane per batch row walks t = 0 .. T-1: z = zx[t] + m_{t-1} W_h (W_h = kernel[1:], 20 x 80, read through
@@ -27,7 +27,8 @@
 namespace nnv {
 namespace {
 
-typedef float __attribute__((address_space(4))) cfloat;   // constant address space: uniform loads become s_load
+typedef float __attribute__((address_space(4))) cfloat;
+using f32x2 = __attribute__((ext_vector_type(2))) float;   // constant address space: uniform loads become s_load
 
 __device__ __forceinline__ float sigmoid_f(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z)); }
 __device__ __forceinline__ float tanh_f(float z) {
@@ -73,10 +74,20 @@ __global__ __launch_bounds__(64) void lstm_seq_fwd_kernel(const float *__restric
     unsigned long long wp = reinterpret_cast<unsigned long long>(wh);
     asm volatile("" : "+s"(wp));
     const cfloat *w = reinterpret_cast<const cfloat *>(wp);
+    // two gate columns per instruction (v_pk_fma_f32: the weight pair is an aligned SGPR pair, m_k is broadcast): a lone
+    // wave is bound by instruction issue, and a packed FMA issues in the time of a scalar one
 #pragma unroll
-    for (int k = 0; k < H; ++k)
+    for (int k = 0; k < H; ++k) {
+      const f32x2 mk = {m[k], m[k]};
 #pragma unroll
-      for (int g = 0; g < 4 * H; ++g) z[g] = __builtin_fmaf(m[k], w[k * 4 * H + g], z[g]);
+      for (int g = 0; g < 4 * H; g += 2) {
+        const f32x2 wv = {w[k * 4 * H + g], w[k * 4 * H + g + 1]};
+        const f32x2 zv = {z[g], z[g + 1]};
+        const f32x2 r = __builtin_elementwise_fma(mk, wv, zv);
+        z[g] = r[0];
+        z[g + 1] = r[1];
+      }
+    }
     float *go = gates + static_cast<int64_t>(t) * 4 * H * B + b;
     float *co = c_all + static_cast<int64_t>(t) * H * B + b;
     float *mo = m_all + static_cast<int64_t>(t) * H * B + b;
@@ -139,15 +150,15 @@ __global__ __launch_bounds__(64) void lstm_seq_bwd_kernel(const float *__restric
     const cfloat *w = reinterpret_cast<const cfloat *>(wp);
 #pragma unroll
     for (int k = 0; k < H; ++k) {
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four chains per output: the sum is not one serial FMA chain
+      f32x2 sa = {0.f, 0.f}, sb = {0.f, 0.f};           // packed FMAs, two chains of pairs per output
 #pragma unroll
       for (int g = 0; g < 4 * H; g += 4) {
-        s0 = __builtin_fmaf(dzr[g], w[k * 4 * H + g], s0);
-        s1 = __builtin_fmaf(dzr[g + 1], w[k * 4 * H + g + 1], s1);
-        s2 = __builtin_fmaf(dzr[g + 2], w[k * 4 * H + g + 2], s2);
-        s3 = __builtin_fmaf(dzr[g + 3], w[k * 4 * H + g + 3], s3);
+        const f32x2 d0 = {dzr[g], dzr[g + 1]}, d1 = {dzr[g + 2], dzr[g + 3]};
+        const f32x2 w0 = {w[k * 4 * H + g], w[k * 4 * H + g + 1]}, w1 = {w[k * 4 * H + g + 2], w[k * 4 * H + g + 3]};
+        sa = __builtin_elementwise_fma(d0, w0, sa);
+        sb = __builtin_elementwise_fma(d1, w1, sb);
       }
-      dmc[k] = (s0 + s1) + (s2 + s3);
+      dmc[k] = (sa[0] + sa[1]) + (sb[0] + sb[1]);
     }
   }
 #pragma unroll
