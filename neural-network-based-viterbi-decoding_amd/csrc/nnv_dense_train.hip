@@ -217,12 +217,19 @@ __global__ __launch_bounds__(kThreads) void dense_bwd_kernel(const BwdParams p) 
   } else {                                             // dZprev[b][i] = (sum over n of dZ[b][n] W[i][n]) act'(H[b][i]), i < K
     const int t = blockIdx.x - p.n_dw_tiles, it = p.Kp / 32;
     const int b0 = 32 * (t / it), i0 = 32 * (t % it);
-    if (!tile_product<true, true>(p.dz, p.Np, p.w, p.Np, b0, i0, p.Np / 32, red, c)) return;
+    // the activations the epilogue multiplies by act'(.) are requested BEFORE the product (an L2-cold load otherwise
+    // sits between the last MFMA and the store); only the finishing waves w < 4 own output registers
     const int i = i0 + (lane & 31);
+    float hv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (w < 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hv[e] = p.h_in[static_cast<int64_t>(b0 + row_of(4 * w + e, half)) * p.Kp + i];
+    }
+    if (!tile_product<true, true>(p.dz, p.Np, p.w, p.Np, b0, i0, p.Np / 32, red, c)) return;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t at = static_cast<int64_t>(b0 + row_of(4 * w + e, half)) * p.Kp + i;
-      p.dz_prev[at] = i < p.K ? c[e] * dact_from_output(p.h_in[at], p.act) : 0.f;
+      p.dz_prev[at] = i < p.K ? c[e] * dact_from_output(hv[e], p.act) : 0.f;
     }
   }
 }
