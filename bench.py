@@ -225,8 +225,8 @@ def other_baseline_configs(dev, steps: int):
                      "value": n_blocks / (ms * 1e-3), "unit": "blocks/s", "ms_per_launch": ms, "dtype": "f32",
                      "ber": float(c[0] / c[2]), "roofline_frac_of_fp32_mfma_peak": tf / MFMA_PEAK_TFLOPS["f32"],
                      "class_tiles_in_lds": netm.launch_info(n)["class_tiles_in_lds"], "class_tiles": dims[-1] // 32,
-                     # K1w ("split": four waves per 32-row tile, weights from L2) serves short inputs of three-hidden-layer
-                     # fp32 networks, K1 ("persistent") everything else; the two are bit-identical (tests/test_gpu_split.py)
+                     # K1w ("split": four waves per 32-row tile, weights from L2) serves short inputs (<= 32 k rows) of fp32
+                     # networks, K1 ("persistent") everything else; the two are bit-identical (tests/test_gpu_split.py)
                      "kernel": netm.path_for(n)}
         if netm.path_for(n) == "split":      # the same call through K1, for the record
             netm.set_path("persistent")

@@ -184,8 +184,8 @@ int32_t nnv_mlp_decode_host_f32(nnv_mlp_handle *h, const float *x_host,
  * waves that share each layer's tiles and read the weights from L2: the latency shape for short inputs (BASELINE
  * configs[0], 2,000 rows: the call the reference makes as predictions_tensor.eval(feed_dict={x: test_set}),
  * src/fnn_viterbi.py:606-610, with a small test_set).  Same packed network, same arithmetic, same decision rule: the
- * two return the same classes bit for bit.  AUTO (the default) takes K1w up to 1,024 tiles for fp32 networks with the
- * reference's hidden widths (128, 64, 32) and K1 otherwise; nnv_mlp_decode_binned_f32 and nnv_mlp_forward_f32 always
+ * two return the same classes bit for bit.  AUTO (the default) takes K1w up to 1,024 tiles for fp32 networks (every
+ * shape nnv_mlp_prepack takes) and K1 otherwise; nnv_mlp_decode_binned_f32 and nnv_mlp_forward_f32 always
  * run K1.  nnv_mlp_set_path(SPLIT) on a network K1w does not take: NNV_ERR_UNSUPPORTED_SHAPE, nothing changes.  Not to
  * be called while another thread decodes with the same handle.
  */

@@ -17,7 +17,8 @@
 // are merged by (value, then lower index), which is the first maximum in class order whatever the dealing.  Same
 // outputs as K1 on the same rows, bit for bit (tests/test_gpu_split.py).
 //
-// fp32, the reference's hidden widths (128, 64, 32: src/fnn_viterbi.py:35-37), class layers of any K1 size; classes,
+// fp32, the first one to three of the reference's hidden widths (128, 64, 32: src/fnn_viterbi.py:35-37) exactly as K1
+// takes them, class layers of any K1 size; classes,
 // int64 classes, bit matrix and the four counters out; no per-SNR bins, no debug activations (those calls stay on K1).
 #include "nnv_internal.h"
 
@@ -87,20 +88,23 @@ __device__ __forceinline__ f32x16 xch_get(const float *x, int t, int lane) {
 
 constexpr int kA = 4, kB = 2, kC = 1;   // 32-wide tiles of the hidden layers 128, 64, 32
 
-template <int G1>
+// NHID hidden layers: the first NHID of the reference's widths (128, 64, 32), as in K1
+template <int G1, int NHID>
 __global__ __launch_bounds__(256) void mlp_decode_split_kernel(const DecodeParams p) {
   __shared__ __attribute__((aligned(16))) float xa[kA * kXT];   // h1, four tiles
   __shared__ __attribute__((aligned(16))) float xb[kB * kXT];   // h2, two tiles
   __shared__ float win_v[4][32];                                 // the waves' winners per row: value, class
   __shared__ int win_i[4][32];
   constexpr int G = kFragGroupFloats;
-  constexpr int W1F = kA * G1 * G, W2F = kB * kA * 4 * G, W3F = kC * kB * 4 * G, HIDF = W1F + W2F + W3F;
+  constexpr int W1F = kA * G1 * G, W2F = NHID >= 2 ? kB * kA * 4 * G : 0, W3F = NHID >= 3 ? kC * kB * 4 * G : 0, HIDF = W1F + W2F + W3F;
+  constexpr int KTO = NHID == 1 ? kA : (NHID == 2 ? kB : kC);   // 32-wide k-tiles of the class layer's input
+  constexpr int GPT = 4 * KTO;                                   // fragment groups per class tile
   const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * kRowsPerTile + j;
   const float *const g_out = p.wpack + HIDF;
-  const float *const g_bias = g_out + static_cast<int64_t>(p.mt_out) * 4 * G;   // b1 (128) | b2 (64) | b3 (32) | class (32 mt_out)
-  const float *const g_bo = g_bias + 32 * (kA + kB + kC);
+  const float *const g_bias = g_out + static_cast<int64_t>(p.mt_out) * GPT * G;   // b1 (128) | b2 (64) | b3 (32) | class (32 mt_out)
+  const float *const g_bo = g_bias + 32 * (kA + (NHID >= 2 ? kB : 0) + (NHID >= 3 ? kC : 0));
 
   // ---------------- P0: layer 1, tile w ----------------
   float xr[4 * G1];
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(256) void mlp_decode_split_kernel(const DecodeParam
   }
   f32x4 f1[G1];
   load_groups<G1>(p.wpack + static_cast<int64_t>(w) * G1 * G, lane, f1);
-  f32x4 f2[kA * 4];
-  if (w < kB) load_groups<kA * 4>(p.wpack + W1F + static_cast<int64_t>(w) * kA * 4 * G, lane, f2);
+  f32x4 f2[kA * 4] = {};
+  if (NHID >= 2 && w < kB) load_groups<kA * 4>(p.wpack + W1F + static_cast<int64_t>(w) * kA * 4 * G, lane, f2);
   {
     f32x16 acc = bias_acc(g_bias + 32 * w, half);
 #pragma unroll
@@ -123,29 +127,37 @@ __global__ __launch_bounds__(256) void mlp_decode_split_kernel(const DecodeParam
     act_r(acc);
     xch_put(xa, w, acc, lane);
   }
-  f32x4 f3[kB * 4];
-  load_groups<kB * 4>(p.wpack + W1F + W2F, lane, f3);
+  f32x4 f3[kB * 4] = {};
+  if (NHID >= 3) load_groups<kB * 4>(p.wpack + W1F + W2F, lane, f3);
   __syncthreads();   // 1: h1
 
   // ---------------- P1: layer 2, tile w (waves 0, 1) ----------------
-  if (w < kB) {
-    f32x16 h1[kA];
+  if constexpr (NHID >= 2) {
+    if (w < kB) {
+      f32x16 h1[kA];
 #pragma unroll
-    for (int t = 0; t < kA; ++t) h1[t] = xch_get(xa, t, lane);
-    f32x16 acc = chain<kA>(h1, f2, bias_acc(g_bias + 32 * kA + 32 * w, half));
-    act_r(acc);
-    xch_put(xb, w, acc, lane);
+      for (int t = 0; t < kA; ++t) h1[t] = xch_get(xa, t, lane);
+      f32x16 acc = chain<kA>(h1, f2, bias_acc(g_bias + 32 * kA + 32 * w, half));
+      act_r(acc);
+      xch_put(xb, w, acc, lane);
+    }
+    __syncthreads();   // 2: h2
   }
-  __syncthreads();   // 2: h2
 
   // ---------------- P2: layer 3 (every wave), then this wave's class tiles ----------------
-  f32x16 h3[kC];
-  {
+  f32x16 hl[KTO];      // the class layer's input: h1 (one hidden layer), h2 (two) or h3 (three)
+  if constexpr (NHID == 1) {
+#pragma unroll
+    for (int t = 0; t < kA; ++t) hl[t] = xch_get(xa, t, lane);
+  } else if constexpr (NHID == 2) {
+#pragma unroll
+    for (int t = 0; t < kB; ++t) hl[t] = xch_get(xb, t, lane);
+  } else {
     f32x16 h2[kB];
 #pragma unroll
     for (int t = 0; t < kB; ++t) h2[t] = xch_get(xb, t, lane);
-    h3[0] = chain<kB>(h2, f3, bias_acc(g_bias + 32 * (kA + kB), half));
-    act_r(h3[0]);
+    hl[0] = chain<kB>(h2, f3, bias_acc(g_bias + 32 * (kA + kB), half));
+    act_r(hl[0]);
   }
   // running first maximum over the wave's tiles (ascending), on the clamped pre-activations: K1's rule
   float best = -__builtin_inff();
@@ -153,18 +165,18 @@ __global__ __launch_bounds__(256) void mlp_decode_split_kernel(const DecodeParam
   f32x16 keep;
 #pragma unroll
   for (int r = 0; r < 16; ++r) keep[r] = 0.f;
-  f32x4 fc[4] = {}, fn[4] = {};
+  f32x4 fc[GPT] = {}, fn[GPT] = {};
   f32x16 bc = keep, bn = keep;
   if (w < p.mt_out) {
-    load_groups<4>(g_out + static_cast<int64_t>(w) * 4 * G, lane, fc);
+    load_groups<GPT>(g_out + static_cast<int64_t>(w) * GPT * G, lane, fc);
     bc = bias_acc(g_bo + 32 * w, half);
   }
   for (int mt = w; mt < p.mt_out; mt += 4) {
     if (mt + 4 < p.mt_out) {   // the next tile's fragments and bias, requested before this tile's MFMAs
-      load_groups<4>(g_out + static_cast<int64_t>(mt + 4) * 4 * G, lane, fn);
+      load_groups<GPT>(g_out + static_cast<int64_t>(mt + 4) * GPT * G, lane, fn);
       bn = bias_acc(g_bo + 32 * (mt + 4), half);
     }
-    f32x16 acc = chain<kC>(h3, fc, bc);
+    f32x16 acc = chain<KTO>(hl, fc, bc);
     if ((mt + 1) * 32 > p.n_classes) {   // last tile of a class count that is not a multiple of 32
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(256) void mlp_decode_split_kernel(const DecodeParam
 #pragma unroll
     for (int r = 0; r < 16; ++r) keep[r] = c ? acc[r] : keep[r];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) fc[q] = fn[q];
+    for (int q = 0; q < GPT; ++q) fc[q] = fn[q];
     bc = bn;
   }
   int bidx;
@@ -215,8 +227,8 @@ __global__ __launch_bounds__(256) void mlp_decode_split_kernel(const DecodeParam
     float tb = -__builtin_inff();
     int ti = 0;
     for (int mt = w; mt < p.mt_out; mt += 4) {
-      load_groups<4>(g_out + static_cast<int64_t>(mt) * 4 * G, lane, fc);
-      const f32x16 acc = chain<kC>(h3, fc, bias_acc(g_bo + 32 * mt, half));
+      load_groups<GPT>(g_out + static_cast<int64_t>(mt) * GPT * G, lane, fc);
+      const f32x16 acc = chain<KTO>(hl, fc, bias_acc(g_bo + 32 * mt, half));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = 32 * mt + 4 * half + 8 * (r >> 2) + (r & 3);
@@ -275,24 +287,30 @@ __global__ __launch_bounds__(256) void mlp_decode_split_kernel(const DecodeParam
 }
 
 using SplitFn = void (*)(const DecodeParams);
-SplitFn split_fn(int g1) {
+template <int NHID>
+SplitFn split_fn_g(int g1) {
   switch (g1) {
-    case 1: return mlp_decode_split_kernel<1>;
-    case 2: return mlp_decode_split_kernel<2>;
-    case 3: return mlp_decode_split_kernel<3>;
-    case 4: return mlp_decode_split_kernel<4>;
+    case 1: return mlp_decode_split_kernel<1, NHID>;
+    case 2: return mlp_decode_split_kernel<2, NHID>;
+    case 3: return mlp_decode_split_kernel<3, NHID>;
+    case 4: return mlp_decode_split_kernel<4, NHID>;
     default: return nullptr;   // rows longer than 32 soft bits do not reach K1 at all
   }
+}
+SplitFn split_fn(int g1, int nhid) {
+  return nhid == 1 ? split_fn_g<1>(g1) : (nhid == 2 ? split_fn_g<2>(g1) : (nhid == 3 ? split_fn_g<3>(g1) : nullptr));
 }
 
 }  // namespace
 
 bool split_supported(const PackedShape &s) {
-  return s.precision == kPrecF32 && s.nhid == 3 && s.mt[0] == kA && s.mt[1] == kB && s.mt[2] == kC && split_fn(s.g1) != nullptr;
+  if (s.precision != kPrecF32 || s.nhid < 1 || s.nhid > 3 || s.mt[0] != kA) return false;
+  if ((s.nhid >= 2 && s.mt[1] != kB) || (s.nhid >= 3 && s.mt[2] != kC)) return false;
+  return split_fn(s.g1, s.nhid) != nullptr;
 }
 
 nnv_status split_launch(const PackedShape &s, const DecodeParams &p, hipStream_t stream) {
-  const SplitFn fn = split_supported(s) ? split_fn(s.g1) : nullptr;
+  const SplitFn fn = split_supported(s) ? split_fn(s.g1, s.nhid) : nullptr;
   if (!fn || p.act || p.n_bins > 1) return NNV_ERR_UNSUPPORTED_SHAPE;
   if (p.n_tiles > 0x7fffffffLL) return NNV_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(p.n_tiles)), dim3(256), 0, stream, p);

@@ -277,7 +277,7 @@ class PackedMLP:
     def set_path(self, path: str) -> None:
         """Pin ``decode`` to one kernel: "persistent" (K1: the network staged into LDS once per workgroup, tiles walked
         wave by wave -- the throughput shape), "split" (K1w: a workgroup of four waves per 32-row tile, weights from L2
-        -- the latency shape for short inputs; fp32 networks with the reference's hidden widths only, else raises) or
+        -- the latency shape for short inputs; fp32 networks only, else raises) or
         "auto" (K1w up to 1,024 tiles where it applies, the default).  The two return the same classes bit for bit."""
         _cabi.check(self._lib.nnv_mlp_set_path(self._handle, _cabi.NNV_MLP_PATH[path]), "nnv_mlp_set_path")
 

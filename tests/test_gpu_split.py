@@ -8,10 +8,10 @@ import nnviterbi_amd  # noqa: F401
 from oracle import fnn_oracle as FO
 
 
-def _net(n_in, n_classes, rng, scale=1.0):
-    dims = [n_in, 128, 64, 32, n_classes]
-    Ws = [(rng.randn(dims[i], dims[i + 1]) * scale * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(4)]
-    bs = [(rng.randn(dims[i + 1]) * 0.1).astype(np.float32) for i in range(4)]
+def _net(n_in, n_classes, rng, scale=1.0, nhid=3):
+    dims = [n_in] + [128, 64, 32][:nhid] + [n_classes]
+    Ws = [(rng.randn(dims[i], dims[i + 1]) * scale * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(nhid + 1)]
+    bs = [(rng.randn(dims[i + 1]) * 0.1).astype(np.float32) for i in range(nhid + 1)]
     return Ws, bs
 
 
@@ -24,17 +24,19 @@ def _decode(net, x, labels, path, tile_bits):
     return r
 
 
-SHAPES = [(14, 128, 7), (16, 256, 8), (20, 1024, 10), (12, 64, 6), (13, 100, 7), (32, 4096, 12), (7, 33, 6), (26, 8192, 13)]
+SHAPES = [(14, 128, 7, 3), (16, 256, 8, 3), (20, 1024, 10, 3), (12, 64, 6, 3), (13, 100, 7, 3), (32, 4096, 12, 3),
+          (7, 33, 6, 3), (26, 8192, 13, 3),
+          (20, 1024, 10, 2), (14, 100, 7, 2), (16, 256, 8, 1), (9, 50, 6, 1), (24, 2048, 11, 1)]   # BASELINE configs[1] is a 2-hidden-layer network
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_in,n_classes,tile_bits", SHAPES)
+@pytest.mark.parametrize("n_in,n_classes,tile_bits,nhid", SHAPES)
 @pytest.mark.parametrize("n_rows", [1, 31, 32, 33, 2000])
-def test_split_equals_persistent_bit_for_bit(n_in, n_classes, tile_bits, n_rows):
+def test_split_equals_persistent_bit_for_bit(n_in, n_classes, tile_bits, nhid, n_rows):
     import torch
     from nnviterbi_amd.decoder import PackedMLP
-    rng = np.random.RandomState(n_in * 7 + n_rows)
-    Ws, bs = _net(n_in, n_classes, rng)
+    rng = np.random.RandomState(n_in * 7 + n_rows + nhid)
+    Ws, bs = _net(n_in, n_classes, rng, nhid=nhid)
     x = torch.tensor(rng.randn(n_rows, n_in).astype(np.float32), device="cuda")
     labels = torch.tensor(rng.randint(0, n_classes, n_rows).astype(np.int32), device="cuda")
     net = PackedMLP(Ws, bs)
@@ -77,20 +79,14 @@ def test_split_flat_top_rows_follow_the_tanh_argmax():
 
 
 @pytest.mark.gpu
-def test_split_refuses_other_networks_and_precisions():
+def test_split_refuses_the_16_bit_precisions():
     from nnviterbi_amd import _cabi
     from nnviterbi_amd.decoder import PackedMLP
     rng = np.random.RandomState(1)
-    dims = [14, 128, 64, 128]
-    Ws = [(rng.randn(dims[i], dims[i + 1]) * 0.2).astype(np.float32) for i in range(3)]
-    bs = [np.zeros(dims[i + 1], np.float32) for i in range(3)]
-    net = PackedMLP(Ws, bs)                              # two hidden layers: K1 only
-    with pytest.raises(_cabi.NNViterbiError):
-        net.set_path("split")
-    assert net.path_for(100) == "persistent"
-    net.close()
     Ws, bs = _net(14, 128, rng)
-    net = PackedMLP(Ws, bs, precision="f16x3")           # 16-bit operands: K1 only
-    with pytest.raises(_cabi.NNViterbiError):
-        net.set_path("split")
-    net.close()
+    for precision in ("f16x3", "f16"):
+        net = PackedMLP(Ws, bs, precision=precision)     # 16-bit operands: K1 only
+        with pytest.raises(_cabi.NNViterbiError):
+            net.set_path("split")
+        assert net.path_for(100) == "persistent"
+        net.close()
