@@ -377,101 +377,117 @@ def next_row_paths(dev, steps: int):
     out["bitwise_one_position"] = {"workload": f"1 bit position x {nb} rows, {cfgb.n_input}-{cfgb.n_hidden_1}-2 ReLU, exact fp32, "
                                                f"untrained weights ({4 * cfgb.n_input + 1} algorithmic bytes per row)", **res1}
     del xb
-    # the reference's training step (src/fnn_viterbi.py:549-594: softmax-CE on the tanh outputs
-    # + beta l2(h1..h3), TF-1 Adam, batch 256) on BASELINE configs[2]'s network -- K7 (csrc/nnv_train.hip: forward + loss +
-    # backward in one launch, Adam + repack in a second) beside PyTorch autograd replayed from a HIP graph.
     from nnviterbi_amd import training
-    cfgt = fv.DecoderConfig(block_length=TILE_BITS)
-    wt, bt = fv.initialize_weights(cfgt, rng=np.random.RandomState(0))
-    bs_t, steps_t = int(cfgt.batch_size), 250
-    xt = torch.randn((steps_t * bs_t, cfgt.n_input), device=dev, generator=g)
-    lt = torch.randint(0, cfgt.n_classes, (steps_t * bs_t,), device=dev, dtype=torch.int32, generator=g)
-    nt = training.NativeFNNTrainer(wt, bt, cfgt.learning_rate, cfgt.beta_regularization, bs_t, device=dev)
-    nt.steps(xt, lt, steps_t)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    nt.steps(xt, lt, steps_t)             # as train_network calls it: per-step costs are not assembled, their sum is exported
-    torch.cuda.synchronize(dev)
-    us_native = (time.perf_counter() - t0) / steps_t * 1e6
-    costs = nt.steps(xt, lt, steps_t, want_costs=True)      # outside the timed region: shows the step trains
-    nt.close()
-    yt = torch.nn.functional.one_hot(lt.long(), cfgt.n_classes).to(torch.float32)
-    at = training.FNNTrainer(wt, bt, cfgt.learning_rate, cfgt.beta_regularization, device=dev)
-    run = training.GraphedStep(lambda xb_, yb_: at.step(xb_, yb_), at.parameters(), at.opt, [xt[:bs_t], yt[:bs_t]])
-    for i in range(10):
-        run(xt[i * bs_t:(i + 1) * bs_t], yt[i * bs_t:(i + 1) * bs_t])
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(100):
-        run(xt[i * bs_t:(i + 1) * bs_t], yt[i * bs_t:(i + 1) * bs_t])
-    torch.cuda.synchronize(dev)
-    us_auto = (time.perf_counter() - t0) / 100 * 1e6
-    macs = sum(int(np.prod(v.shape)) for v in wt.values())
-    out["training_step"] = {"workload": f"the reference's training step, batch {bs_t}, {'-'.join(str(d) for d in fv.layer_dims(cfgt))}, "
-                                        f"{steps_t} consecutive steps in one call, random rows",
-                            "two_kernel_step_K7": {"us_per_step": us_native, "steps_per_s": 1e6 / us_native,
-                                                   "algorithmic_tflops": 6 * macs * bs_t / (us_native * 1e-6) / 1e12,
-                                                   "cost_first_last": [float(costs[0].item()), float(costs[-1].item())]},
-                            "autograd_from_hip_graph": {"us_per_step": us_auto, "graph_captured": bool(run.captured)}}
-    del xt, lt, yt
-    # SURVEY.md section 8(f) ranks 2 and 4, the training side: the bit-wise and the sliding-window decoders' step
-    # (src/fnn_viterbi_bitwise.py:438-452 batch 1000, src/fnn_viterbi_seq_predict.py:475-489 batch 100 over windows of one
-    # stream) through K8 (csrc/nnv_dense_train.hip: 2 L + 1 launches per step)
-    dense = {}
-    for name, dims, act, bs_d, steps_d, stride in (("bitwise_1036_30_2_relu", [1036, 30, 2], "relu", 1000, 300, None),
-                                                   ("sliding_window_200_500x4_2_tanh", [200, 500, 500, 500, 500, 2], "tanh", 100, 1000, 2)):
-        rng = np.random.RandomState(0)
-        Wd = [(rng.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
-        Bd = [np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 1)]
-        rs = dims[0] if stride is None else stride
-        flat = torch.randn(((steps_d * bs_d - 1) * rs + dims[0],), device=dev, generator=g)
-        labd = torch.randint(0, 2, (steps_d * bs_d,), device=dev, dtype=torch.int32, generator=g)
-        dt_ = training.NativeDenseTrainer(Wd, Bd, act, 2e-4, 1e-4, bs_d, reg_layers=(0, 1) if len(dims) > 3 else (0,), device=dev)
-        dt_.steps(flat, labd, steps_d, row_stride=rs, step_stride=bs_d * rs)
+
+    def _leg_k7():
+        # the reference's training step (src/fnn_viterbi.py:549-594: softmax-CE on the tanh outputs
+        # + beta l2(h1..h3), TF-1 Adam, batch 256) on BASELINE configs[2]'s network -- K7 (csrc/nnv_train.hip: forward + loss +
+        # backward in one launch, Adam + repack in a second) beside PyTorch autograd replayed from a HIP graph.
+        cfgt = fv.DecoderConfig(block_length=TILE_BITS)
+        wt, bt = fv.initialize_weights(cfgt, rng=np.random.RandomState(0))
+        bs_t, steps_t = int(cfgt.batch_size), 250
+        xt = torch.randn((steps_t * bs_t, cfgt.n_input), device=dev, generator=g)
+        lt = torch.randint(0, cfgt.n_classes, (steps_t * bs_t,), device=dev, dtype=torch.int32, generator=g)
+        nt = training.NativeFNNTrainer(wt, bt, cfgt.learning_rate, cfgt.beta_regularization, bs_t, device=dev)
+        nt.steps(xt, lt, steps_t)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        dt_.steps(flat, labd, steps_d, row_stride=rs, step_stride=bs_d * rs)
+        nt.steps(xt, lt, steps_t)             # as train_network calls it: per-step costs are not assembled, their sum is exported
         torch.cuda.synchronize(dev)
-        us_d = (time.perf_counter() - t0) / steps_d * 1e6
-        cd = dt_.steps(flat, labd, steps_d, row_stride=rs, step_stride=bs_d * rs, want_costs=True)   # outside the timed region
-        dt_.close()
-        macs_d = sum(int(np.prod(w.shape)) for w in Wd)
-        dense[name] = {"batch": bs_d, "launches_per_step": 2 * (len(dims) - 1) + 1, "us_per_step": us_d,
-                       "algorithmic_tflops": 6 * macs_d * bs_d / (us_d * 1e-6) / 1e12,
-                       "cost_first_last": [float(cd[0].item()), float(cd[-1].item())]}
-        del flat, labd
-    out["dense_training_steps_K8"] = dense
-    # SURVEY.md section 8(f) rank 4, the training side: the recurrent decoder's step at its default shape (LSTM(20) over 200
-    # coded symbols + 200 decoder steps, batch 100, src/rnn_viterbi.py:28-92, 277-316), both recurrences in K9
-    # (csrc/nnv_lstm_train.hip), replayed from a HIP graph.  The unrolled PyTorch graph (45 ms per step) is not timed here:
-    # capturing its 16,000 kernels takes longer than this whole leg (tools/bench_lstm_trainer.py has both).
-    from nnviterbi_amd import rnn_viterbi as rv
-    cfr = rv.RNNDecoderConfig()
-    mdl = rv.build_seq2seq_model(cfr, rng=np.random.RandomState(0))
-    Tr, Br = cfr.encoded_length, cfr.batch_size
-    er = torch.randn((Tr, Br), device=dev, generator=g)
-    dr = torch.randint(0, 2, (Tr, Br), device=dev, generator=g).float()
-    tr_ = torch.randn((Tr, Br, 1), device=dev, generator=g)
-    Pr = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in mdl["params"].items()}
-    optr = training.TFAdam(list(Pr.values()), lr=cfr.learning_rate)
+        us_native = (time.perf_counter() - t0) / steps_t * 1e6
+        costs = nt.steps(xt, lt, steps_t, want_costs=True)      # outside the timed region: shows the step trains
+        nt.close()
+        yt = torch.nn.functional.one_hot(lt.long(), cfgt.n_classes).to(torch.float32)
+        at = training.FNNTrainer(wt, bt, cfgt.learning_rate, cfgt.beta_regularization, device=dev)
+        run = training.GraphedStep(lambda xb_, yb_: at.step(xb_, yb_), at.parameters(), at.opt, [xt[:bs_t], yt[:bs_t]])
+        for i in range(10):
+            run(xt[i * bs_t:(i + 1) * bs_t], yt[i * bs_t:(i + 1) * bs_t])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(100):
+            run(xt[i * bs_t:(i + 1) * bs_t], yt[i * bs_t:(i + 1) * bs_t])
+        torch.cuda.synchronize(dev)
+        us_auto = (time.perf_counter() - t0) / 100 * 1e6
+        macs = sum(int(np.prod(v.shape)) for v in wt.values())
+        out["training_step"] = {"workload": f"the reference's training step, batch {bs_t}, {'-'.join(str(d) for d in fv.layer_dims(cfgt))}, "
+                                            f"{steps_t} consecutive steps in one call, random rows",
+                                "two_kernel_step_K7": {"us_per_step": us_native, "steps_per_s": 1e6 / us_native,
+                                                       "algorithmic_tflops": 6 * macs * bs_t / (us_native * 1e-6) / 1e12,
+                                                       "cost_first_last": [float(costs[0].item()), float(costs[-1].item())]},
+                                "autograd_from_hip_graph": {"us_per_step": us_auto, "graph_captured": bool(run.captured)}}
+        del xt, lt, yt
+    try:
+        _leg_k7()
+    except Exception as e:   # noqa: BLE001  (a trainer leg must not cost the other records)
+        out["training_step"] = {"error": f"{type(e).__name__}: {e}"}
+    def _leg_k8():
+        # SURVEY.md section 8(f) ranks 2 and 4, the training side: the bit-wise and the sliding-window decoders' step
+        # (src/fnn_viterbi_bitwise.py:438-452 batch 1000, src/fnn_viterbi_seq_predict.py:475-489 batch 100 over windows of one
+        # stream) through K8 (csrc/nnv_dense_train.hip: 2 L + 1 launches per step)
+        dense = {}
+        for name, dims, act, bs_d, steps_d, stride in (("bitwise_1036_30_2_relu", [1036, 30, 2], "relu", 1000, 300, None),
+                                                       ("sliding_window_200_500x4_2_tanh", [200, 500, 500, 500, 500, 2], "tanh", 100, 1000, 2)):
+            rng = np.random.RandomState(0)
+            Wd = [(rng.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+            Bd = [np.zeros(dims[i + 1], np.float32) for i in range(len(dims) - 1)]
+            rs = dims[0] if stride is None else stride
+            flat = torch.randn(((steps_d * bs_d - 1) * rs + dims[0],), device=dev, generator=g)
+            labd = torch.randint(0, 2, (steps_d * bs_d,), device=dev, dtype=torch.int32, generator=g)
+            dt_ = training.NativeDenseTrainer(Wd, Bd, act, 2e-4, 1e-4, bs_d, reg_layers=(0, 1) if len(dims) > 3 else (0,), device=dev)
+            dt_.steps(flat, labd, steps_d, row_stride=rs, step_stride=bs_d * rs)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            dt_.steps(flat, labd, steps_d, row_stride=rs, step_stride=bs_d * rs)
+            torch.cuda.synchronize(dev)
+            us_d = (time.perf_counter() - t0) / steps_d * 1e6
+            cd = dt_.steps(flat, labd, steps_d, row_stride=rs, step_stride=bs_d * rs, want_costs=True)   # outside the timed region
+            dt_.close()
+            macs_d = sum(int(np.prod(w.shape)) for w in Wd)
+            dense[name] = {"batch": bs_d, "launches_per_step": 2 * (len(dims) - 1) + 1, "us_per_step": us_d,
+                           "algorithmic_tflops": 6 * macs_d * bs_d / (us_d * 1e-6) / 1e12,
+                           "cost_first_last": [float(cd[0].item()), float(cd[-1].item())]}
+            del flat, labd
+        out["dense_training_steps_K8"] = dense
+    try:
+        _leg_k8()
+    except Exception as e:   # noqa: BLE001  (a trainer leg must not cost the other records)
+        out["dense_training_steps_K8"] = {"error": f"{type(e).__name__}: {e}"}
+    def _leg_k9():
+        # SURVEY.md section 8(f) rank 4, the training side: the recurrent decoder's step at its default shape (LSTM(20) over 200
+        # coded symbols + 200 decoder steps, batch 100, src/rnn_viterbi.py:28-92, 277-316), both recurrences in K9
+        # (csrc/nnv_lstm_train.hip), replayed from a HIP graph.  The unrolled PyTorch graph (45 ms per step) is not timed here:
+        # capturing its 16,000 kernels takes longer than this whole leg (tools/bench_lstm_trainer.py has both).
+        from nnviterbi_amd import rnn_viterbi as rv
+        cfr = rv.RNNDecoderConfig()
+        mdl = rv.build_seq2seq_model(cfr, rng=np.random.RandomState(0))
+        Tr, Br = cfr.encoded_length, cfr.batch_size
+        er = torch.randn((Tr, Br), device=dev, generator=g)
+        dr = torch.randint(0, 2, (Tr, Br), device=dev, generator=g).float()
+        tr_ = torch.randn((Tr, Br, 1), device=dev, generator=g)
+        Pr = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in mdl["params"].items()}
+        optr = training.TFAdam(list(Pr.values()), lr=cfr.learning_rate)
 
-    def rstep(e, d, t):
-        loss = ((t - training.lstm_seq2seq_logits_native(Pr, e, d, 1.0)) ** 2).mean()
-        optr.zero_grad(set_to_none=False)
-        loss.backward()
-        optr.step()
-        return loss.detach()
-    runr = training.GraphedStep(rstep, list(Pr.values()), optr, (er, dr, tr_), False)
-    for _ in range(3):
-        runr(er, dr, tr_)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(50):
-        lr_ = runr(er, dr, tr_)
-    torch.cuda.synchronize(dev)
-    out["recurrent_training_step_K9"] = {"t_enc": Tr, "t_dec": Tr, "batch": Br, "hidden": cfr.encoder_hidden_units,
-                                         "ms_per_step": (time.perf_counter() - t0) / 50 * 1e3,
-                                         "graph_captured": bool(runr.captured), "loss_last": float(lr_)}
+        def rstep(e, d, t):
+            loss = ((t - training.lstm_seq2seq_logits_native(Pr, e, d, 1.0)) ** 2).mean()
+            optr.zero_grad(set_to_none=False)
+            loss.backward()
+            optr.step()
+            return loss.detach()
+        runr = training.GraphedStep(rstep, list(Pr.values()), optr, (er, dr, tr_), False)
+        for _ in range(3):
+            runr(er, dr, tr_)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            lr_ = runr(er, dr, tr_)
+        torch.cuda.synchronize(dev)
+        out["recurrent_training_step_K9"] = {"t_enc": Tr, "t_dec": Tr, "batch": Br, "hidden": cfr.encoder_hidden_units,
+                                             "ms_per_step": (time.perf_counter() - t0) / 50 * 1e3,
+                                             "graph_captured": bool(runr.captured), "loss_last": float(lr_)}
+    try:
+        _leg_k9()
+    except Exception as e:   # noqa: BLE001  (a trainer leg must not cost the other records)
+        out["recurrent_training_step_K9"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
