@@ -563,3 +563,40 @@ def test_c_abi_is_reentrant_from_host_threads(cuda_device):
         t.join(timeout=300)
     assert not errors, errors
     assert results == {k: True for k, _ in specs}, results
+
+
+@pytest.mark.gpu
+def test_bound_decode_is_the_same_decode_with_the_host_work_done_once(cuda_device):
+    """PackedMLP.bound_decode: a prepared call over fixed buffers (serving short inputs) returns what decode() returns,
+    follows in-place refills of x, adds to its counters, and is capturable into a HIP graph."""
+    import torch
+    from nnviterbi_amd.decoder import PackedMLP
+    rng = np.random.RandomState(3)
+    dims = [16, 128, 64, 32, 256]
+    Ws = [(rng.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(4)]
+    bs = [(rng.randn(dims[i + 1]) * 0.1).astype(np.float32) for i in range(4)]
+    net = PackedMLP(Ws, bs)
+    x = torch.tensor(rng.randn(2000, 16).astype(np.float32), device="cuda")
+    labels = torch.tensor(rng.randint(0, 256, 2000).astype(np.int32), device="cuda")
+    call = net.bound_decode(x, labels=labels, tile_bits=8, want_bits=True)
+    ref = net.decode(x, labels=labels, tile_bits=8, want_bits=True)
+    out = call()
+    torch.cuda.synchronize()
+    for k in ("cls32", "bits", "counters"):
+        assert torch.equal(out[k], ref[k]), k
+    x.copy_(torch.tensor(rng.randn(2000, 16).astype(np.float32), device="cuda"))      # refill in place
+    ref2 = net.decode(x, labels=labels, tile_bits=8, want_bits=True)
+    out = call()
+    torch.cuda.synchronize()
+    assert torch.equal(out["cls32"], ref2["cls32"]) and torch.equal(out["counters"], ref["counters"] + ref2["counters"])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        gcall = net.bound_decode(x, tile_bits=8)           # bound to the side stream
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            gcall()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gcall.outputs["cls32"], ref2["cls32"])
+    net.close()
+

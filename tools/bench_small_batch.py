@@ -36,6 +36,20 @@ for b, n_cls in ((8, 256), (10, 1024)):
                 net.decode(x, tile_bits=b)
                 torch.cuda.synchronize()
             row[path + "_us_synced"] = (time.perf_counter() - t0) / 100 * 1e6
+            call = net.bound_decode(x, tile_bits=b)          # the host work of a call done once (serving)
+            for _ in range(20):
+                call()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                call()
+            torch.cuda.synchronize()
+            row[path + "_us_bound_pipelined"] = (time.perf_counter() - t0) / n * 1e6
+            t0 = time.perf_counter()
+            for _ in range(100):
+                call()
+                torch.cuda.synchronize()
+            row[path + "_us_bound_synced"] = (time.perf_counter() - t0) / 100 * 1e6
         res[str(n_rows)] = row
     out[f"b{b}"] = res
     net.close()
