@@ -467,7 +467,7 @@ int32_t nnv_seq2seq_forward_f32(const nnv_seq2seq_handle *h, const float *enc_in
  *   (TF 1.x: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), epsilon 1e-8 OUTSIDE the bias correction)
  *   optional tf.nn.dropout after every hidden tanh                src/fnn_viterbi_mixed_snr.py:596-627
  * for the reference's architecture n_input -> 128 -> 64 -> 32 -> n_classes with n_input <= 32, n_classes <= 256 and a
- * batch of whole 32-row tiles (other shapes: NNV_ERR_UNSUPPORTED_SHAPE; the Python trainer then runs them through
+ * batch of at most 32,768 rows (other shapes: NNV_ERR_UNSUPPORTED_SHAPE; the Python trainer then runs them through
  * PyTorch autograd).  One step = one forward/backward kernel (four waves per 32 rows, every layer's tiles dealt over
  * them and handed over through LDS) + one Adam kernel; no atomics, every sum in a fixed order: results independent of
  * the launch.

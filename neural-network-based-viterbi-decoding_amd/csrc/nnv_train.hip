@@ -53,6 +53,7 @@ struct TrainParams {
   double *cost_acc;          // nullable [n_wg]: their running sums over the steps (read and reset by nnv_train_export)
   const float *mask[3];      // nullable: [B][128], [B][64], [B][32] dropout masks (0/1) of this step
   float inv_keep, inv_batch;
+  int32_t batch;             // rows of the step: the last workgroup's tile may be ragged
 };
 
 __device__ __forceinline__ int neuron_of(int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); }
@@ -239,7 +240,11 @@ __global__ __launch_bounds__(256) void train_fwd_bwd_kernel(const TrainParams p)
   float *const sm = xc + 2 * kXT;               // [4 waves][sum_e | p_label][32 rows]
   const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63, row = lane & 31, half = lane >> 5;
-  const int64_t grow = static_cast<int64_t>(blockIdx.x) * 32 + row;   // global row of the batch
+  // global row of the batch; the rows a ragged last tile lacks shadow the last real row (every load stays in range) and
+  // are given no weight in the loss and in dZ4 -- from there on everything they would contribute is zero
+  const bool valid = static_cast<int64_t>(blockIdx.x) * 32 + row < p.batch;
+  const int64_t grow = valid ? static_cast<int64_t>(blockIdx.x) * 32 + row : p.batch - 1;
+  const float row_weight = valid ? p.inv_batch : 0.f;
   float *const g = p.gpart + static_cast<int64_t>(blockIdx.x) * p.grad_floats;
   constexpr int CP = 32 * MTC;
   constexpr int OWN = (MTC + 3) / 4;            // class tiles of a wave: w, w + 4
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(256) void train_fwd_bwd_kernel(const TrainParams p)
   p_label = (sm[1 * 32 + row] + sm[3 * 32 + row]) + (sm[5 * 32 + row] + sm[7 * 32 + row]);
   if (w == 0) {
     float loss = __builtin_amdgcn_logf(sum_e) * 0.6931471805599453f - p_label;   // -log softmax(p)[label]
-    loss = half == 0 ? loss : 0.f;
+    loss = (half == 0 && valid) ? loss : 0.f;
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) loss += __shfl_xor(loss, off);
     if (lane == 0) {
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(256) void train_fwd_bwd_kernel(const TrainParams p)
         const int c = 32 * mt + neuron_of(r, half);
         const float t = pz[j][r];
         const float sme = c < p.n_classes ? __builtin_amdgcn_exp2f(t * 1.4426950408889634f) * inv_sum : 0.f;
-        pz[j][r] = (sme - (c == label ? 1.0f : 0.f)) * p.inv_batch * (1.0f - t * t);
+        pz[j][r] = (sme - (c == label ? 1.0f : 0.f)) * row_weight * (1.0f - t * t);
       }
       put_tile(zs4, mt, pz[j], row, half);
       share = chain_one(pz[j], b4 + 4 * j, share);
@@ -613,6 +618,7 @@ nnv_status run_fwd_bwd(const nnv_train_handle *h, const float *x, const int32_t 
   for (int l = 0; l < 3; ++l) p.mask[l] = masks ? masks[l] : nullptr;
   p.inv_keep = 1.0f / h->keep_prob;
   p.inv_batch = 1.0f / static_cast<float>(h->batch);
+  p.batch = h->batch;
   switch (h->mtc) {
     case 1: launch_fwd_bwd<1>(p, h->n_wg, s); break;
     case 2: launch_fwd_bwd<2>(p, h->n_wg, s); break;
@@ -672,9 +678,9 @@ int32_t nnv_train_create(const nnv_train_desc *d, nnv_train_handle **out) {
   for (int l = 0; l < 4; ++l)
     if (!d->W_host[l] || !d->b_host[l]) return NNV_ERR_INVALID_ARGUMENT;
   // the reference's architecture only: hidden widths 128, 64, 32; rows of at most 32 soft bits; at most 256 classes;
-  // whole 32-row tiles per batch (its default batch is 256)
+  // any batch up to 32 Ki rows (its default is 256; a ragged last 32-row tile is masked)
   if (d->n_hidden[0] != kH1 || d->n_hidden[1] != kH2 || d->n_hidden[2] != kH3) return NNV_ERR_UNSUPPORTED_SHAPE;
-  if (d->n_input > 32 || d->n_classes > 256 || d->batch_size % 32 != 0 || d->batch_size > 32 * 1024) return NNV_ERR_UNSUPPORTED_SHAPE;
+  if (d->n_input > 32 || d->n_classes > 256 || d->batch_size > 32 * 1024) return NNV_ERR_UNSUPPORTED_SHAPE;
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NNV_ERR_NO_DEVICE;
@@ -687,7 +693,7 @@ int32_t nnv_train_create(const nnv_train_desc *d, nnv_train_handle **out) {
   h->mtc = (d->n_classes + 31) / 32;
   h->cp = 32 * h->mtc;
   h->batch = d->batch_size;
-  h->n_wg = d->batch_size / 32;
+  h->n_wg = (d->batch_size + 31) / 32;
   h->device = dev;
   h->lr = d->learning_rate;
   h->beta_reg = d->beta_regularization;

@@ -222,8 +222,8 @@ class NativeFNNTrainer:
     csrc/nnv_train.hip): forward + loss + backward in one launch (four waves per 32 rows, every layer's
     tiles dealt over them and handed over through LDS), TF-1 Adam + re-packing of the weights in a second.  ~45 launches of a PyTorch-autograd step become 2; the steps of an epoch are issued by ONE call.
 
-    Eligible: the reference's architecture n_in -> 128 -> 64 -> 32 -> n_classes with n_in <= 32, n_classes <= 256, a
-    batch size that is a multiple of 32, on an MI355X.  Labels are class indices (the position of the 1 in the
+    Eligible: the reference's architecture n_in -> 128 -> 64 -> 32 -> n_classes with n_in <= 32, n_classes <= 256, any
+    batch size up to 32,768 (a ragged last 32-row tile is masked), on an MI355X.  Labels are class indices (the position of the 1 in the
     reference's one-hot rows).  Checked against oracle/train_oracle.py like FNNTrainer (tests/test_trainer.py)."""
 
     @staticmethod
@@ -234,7 +234,7 @@ class NativeFNNTrainer:
             return False
         shp = [tuple(np.asarray(weights[k]).shape) for k in ("h1", "h2", "h3", "out")]
         return (shp[0][1], shp[1], shp[2], shp[3][0]) == (128, (128, 64), (64, 32), 32) and shp[0][0] <= 32 \
-            and shp[3][1] <= 256 and batch_size % 32 == 0 and batch_size > 0
+            and shp[3][1] <= 256 and 0 < batch_size <= 32 * 1024
 
     def __init__(self, weights: Dict, biases: Dict, learning_rate: float, beta_regularization: float, batch_size: int,
                  use_dropout: bool = False, keep_prob: float = 0.5, device=None):

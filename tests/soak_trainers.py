@@ -44,19 +44,22 @@ def run(n_cases: int = 200, seed: int = 0, verbose: bool = True):
         rc = [ref.step(rows[t * batch:(t + 1) * batch], y[t * batch:(t + 1) * batch]) for t in range(n_steps)]
         w, b_, e = nt.export()
         w_err = max(np.abs(a.astype(np.float64) - r).max() for a, r in zip(w + b_ + e, ref.Ws + ref.bs + ref.extra))
-        c_err = max(abs(cost - rcost), np.abs(costs - np.array(rc)).max())
+        c_err = max(abs(cost - rcost), abs(float(costs[0]) - rc[0]))        # before any update: a pure kernel quantity
+        later = float(np.abs(costs[1:] - np.array(rc[1:])).max()) if n_steps > 1 else 0.0
         nt.close()
         worst["k8_grad"], worst["k8_w"], worst["k8_cost"] = max(worst["k8_grad"], g_err), max(worst["k8_w"], w_err), max(worst["k8_cost"], c_err)
         # relu kinks make a gradient discontinuous: a pre-activation within rounding of 0 may flip -- report, do not hide
-        # weights: Adam divides by sqrt(v) + 1e-8, so a gradient component of rounding size moves its weight by up to lr
-        # whatever its sign -- the bound on the weights is a fraction of lr, not of the gradient tolerance
-        if g_err > 2e-6 or w_err > max(1e-5, 0.05 * lr) or c_err > 5e-6:
+        # What follows an update is NOT a pure kernel quantity: Adam divides by sqrt(v) + 1e-8, so a gradient component of
+        # rounding size (a ReLU network makes exact zeros) moves its weight by up to lr WHATEVER its sign -- the weights may
+        # differ by up to 2 lr per step and the later costs with them.  Held tightly: the gradients and the first cost;
+        # held loosely (a wrong update rule would break them at once): weights within 2.1 lr per step, later costs 50 lr.
+        if g_err > 2e-6 or c_err > 5e-6 or w_err > 2.1 * lr * n_steps or later > 50 * lr:
             flagged.append(f"K8 case {case}: dims {dims} {kind} batch {batch} reg {reg} stride {stride} lr {lr:.1e}: grad {g_err:.2e} w {w_err:.2e} cost {c_err:.2e}")
             print(flagged[-1], flush=True)
         if case % 4 == 0:   # K7
             n_cls = int(rng.choice([2, 31, 32, 33, 64, 100, 128, 200, 256]))
             n_in = int(rng.randint(2, 33))
-            bk = 32 * int(rng.randint(1, 7))
+            bk = 32 * int(rng.randint(1, 7)) - int(rng.choice([0, 0, 1, 17, 31]))     # whole and ragged last tiles
             drop = rng.rand() < 0.4
             dd = [n_in, 128, 64, 32, n_cls]
             wk = {k: (rng.randn(dd[i], dd[i + 1]) * np.sqrt(2.0 / dd[i])).astype(np.float32) for i, k in enumerate(("h1", "h2", "h3", "out"))}
@@ -79,7 +82,7 @@ def run(n_cases: int = 200, seed: int = 0, verbose: bool = True):
             w_err = max(np.abs(gw[k].astype(np.float64) - r).max() for k, r in zip(("h1", "h2", "h3", "out"), r7.Ws))
             n7.close()
             worst["k7_grad"], worst["k7_w"] = max(worst["k7_grad"], g_err), max(worst["k7_w"], w_err)
-            if g_err > 2e-6 or w_err > 5e-5:     # lr 1e-3: see above
+            if g_err > 2e-6 or w_err > 2.1e-3 * 2:     # lr 1e-3, two steps: see above
                 flagged.append(f"K7 case {case}: n_in {n_in} classes {n_cls} batch {bk} dropout {drop}: grad {g_err:.2e} w {w_err:.2e}")
                 print(flagged[-1], flush=True)
         if verbose and case % 50 == 49:

@@ -204,7 +204,7 @@ def test_native_trainer_refuses_what_it_does_not_take(cuda_device):
     w, bd = fv.initialize_weights(cfg, rng=np.random.RandomState(0))
     assert not training.NativeFNNTrainer.eligible(w, bd, 256)                 # 512 classes
     w6, b6 = fv.initialize_weights(fv.DecoderConfig(block_length=6), rng=np.random.RandomState(0))
-    assert not training.NativeFNNTrainer.eligible(w6, b6, 100)                # batch not a multiple of 32
+    assert training.NativeFNNTrainer.eligible(w6, b6, 100)                    # a ragged last tile is fine
     with pytest.raises(Exception, match="unsupported"):
         training.NativeFNNTrainer(w, bd, 1e-4, 1e-3, 256)
     nt = training.NativeFNNTrainer(w6, b6, 1e-4, 1e-3, 64, use_dropout=True)
@@ -236,7 +236,8 @@ def test_train_network_native_and_autograd_agree(cuda_device, monkeypatch, capsy
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_in,n_classes,batch", [(11, 50, 96), (32, 256, 32), (7, 2, 64), (20, 200, 160)])
+@pytest.mark.parametrize("n_in,n_classes,batch", [(11, 50, 96), (32, 256, 32), (7, 2, 64), (20, 200, 160),
+                                                  (14, 128, 100), (16, 256, 37), (12, 64, 1)])   # ragged last tiles
 def test_native_training_step_on_ragged_shapes(cuda_device, n_in, n_classes, batch):
     """K7 outside the 2^b family: odd row lengths (zero-padded to one 32-wide k-tile), class counts that are not multiples
     of 32 (the padding classes must take no part in the softmax and get no gradient), batches of 1..5 workgroups --
