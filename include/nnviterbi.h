@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NNV_ABI_VERSION 10 /* 10: + nnv_mlp_set_path / nnv_mlp_path_for (K1w, the decode kernel for short inputs); 9: + nnv_lstm_seq_forward_f32 / _backward_f32 (the recurrent decoder's back-propagation through time); 8: + nnv_dense_train_* (the bit-wise / sliding-window decoders' training step); 7: + nnv_train_* (the training step as two kernels); prior: 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS; 6: + nnv_wide_set_path / _get_path, nnv_bitwise_set_path / _path_for (no environment switches any more) */
+#define NNV_ABI_VERSION 11 /* 11: nnv_dense_train_desc.loss (softmax cross-entropy: feed-forward decoders beyond 256 classes train through K8); 10: + nnv_mlp_set_path / nnv_mlp_path_for (K1w, the decode kernel for short inputs); 9: + nnv_lstm_seq_forward_f32 / _backward_f32 (the recurrent decoder's back-propagation through time); 8: + nnv_dense_train_* (the bit-wise / sliding-window decoders' training step); 7: + nnv_train_* (the training step as two kernels); prior: 2: + nnv_check_device, nnv_mlp_decode_host_f32, nnv_bitwise_*; handles carry their device; 3: + NNV_PRECISION_F16; 4: + nnv_bitwise_prepack_ex; 5: + NNV_CODE_CONTINUOUS; 6: + nnv_wide_set_path / _get_path, nnv_bitwise_set_path / _path_for (no environment switches any more) */
 #define NNV_MAX_LAYERS 4 /* dense layers incl. the output layer */
 #define NNV_MLP_MAX_INPUTS 32     /* nnv_mlp_*: row length n_input = 2 b (block_length <= 16); hidden widths: the first 1-3 of
                                      the reference's (128, 64, 32); other shapes: NNV_ERR_UNSUPPORTED_SHAPE -> nnv_wide_* */
@@ -524,15 +524,23 @@ int32_t nnv_train_export(const nnv_train_handle *h, float *const W_host[4], floa
  * next batch) instead of ~60 PyTorch-autograd
  * kernels; exact fp32; every sum in a fixed order.  Handles are mutable state: one caller at a time.
  * ------------------------------------------------------------------------ */
+typedef enum nnv_loss {
+  NNV_LOSS_SIGMOID_CE = 0, /* reduce_mean over rows AND outputs of sigmoid_cross_entropy_with_logits on the activated outputs
+                              (src/fnn_viterbi_bitwise.py:438-441, src/fnn_viterbi_seq_predict.py:475-478); n_output <= 32 */
+  NNV_LOSS_SOFTMAX_CE = 1  /* reduce_mean over rows of softmax_cross_entropy_with_logits on the activated outputs, the
+                              feed-forward decoder's (src/fnn_viterbi.py:549-553); n_output <= NNV_WIDE_MAX_CLASSES */
+} nnv_loss;
+
 typedef struct nnv_dense_train_desc {
   int32_t n_layers;             /* 1..5 */
-  int32_t dims[6];              /* n_input, the hidden widths, n_output (<= 32) */
+  int32_t dims[6];              /* n_input, the hidden widths, n_output */
   int32_t activation;           /* nnv_activation */
   int32_t batch_size;
   float learning_rate, beta_regularization;
   uint32_t reg_layer_mask;      /* bit l: tf.nn.l2_loss(W_l) is part of the cost (both references: layers 0 and 1) */
   const float *W_host[5];       /* [in][out] row-major */
   const float *b_host[5];
+  int32_t loss;                 /* nnv_loss */
   const float *extra_host;      /* nullable: variables that ONLY the regulariser names (the bit-wise decoder's unused h2,
                                    src/fnn_viterbi_bitwise.py:388-397 vs :444-447): gradient beta * value, moved by Adam */
   int64_t n_extra;

@@ -15,7 +15,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("NNV_LIB") or os.path.join(_PKG_DIR, "libnnviterbi_hip.so")
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 
-NNV_ABI_VERSION = 10
+NNV_ABI_VERSION = 11
 NNV_MAX_LAYERS = 4
 NNV_OK = 0
 NNV_CODE_57 = 0
@@ -116,6 +116,7 @@ class DenseTrainDesc(ctypes.Structure):
         ("reg_layer_mask", ctypes.c_uint32),
         ("W_host", ctypes.c_void_p * 5),
         ("b_host", ctypes.c_void_p * 5),
+        ("loss", ctypes.c_int32),
         ("extra_host", ctypes.c_void_p),
         ("n_extra", ctypes.c_int64),
     ]

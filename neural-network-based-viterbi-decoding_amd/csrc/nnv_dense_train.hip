@@ -195,6 +195,62 @@ __global__ __launch_bounds__(kThreads) void dense_fwd_kernel(const FwdParams p) 
   }
 }
 
+// softmax cross-entropy taken on the ACTIVATED outputs (the feed-forward decoder's loss, src/fnn_viterbi.py:549-553:
+// the reference passes the tanh'd class layer as logits), class counts beyond one 32-wide tile: a launch of its own
+// behind the last forward launch.  One wave per row, classes on the lanes (coalesced), three passes: max, sum, dZ.
+struct SoftmaxLossParams {
+  const float *pred;     // [Bp][Np] activated outputs
+  const int32_t *labels; // [B]
+  float *dz;             // [Bp][Np]: rows >= B are never written (they stay 0), columns >= n_out are written 0
+  int32_t B, Np, n_out, act;
+  float inv_b;           // 1 / B
+  float *ce_part;        // [gridDim.x]
+  double *ce_acc;        // nullable [gridDim.x]
+};
+__global__ __launch_bounds__(256) void dense_softmax_loss_kernel(const SoftmaxLossParams p) {
+  __shared__ float ce_wave[4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + w;
+  float loss = 0.f;
+  if (m < p.B) {
+    const float *row = p.pred + static_cast<int64_t>(m) * p.Np;
+    float *drow = p.dz + static_cast<int64_t>(m) * p.Np;
+    const int label = p.labels[m];
+    float mx = -__builtin_inff();
+    for (int c = lane; c < p.n_out; c += 64) mx = fmaxf(mx, row[c]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f, t_label = 0.f;
+    for (int c = lane; c < p.n_out; c += 64) {
+      const float t = row[c];
+      sum += __expf(t - mx);
+      t_label += c == label ? t : 0.f;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sum += __shfl_xor(sum, off);
+      t_label += __shfl_xor(t_label, off);
+    }
+    loss = __logf(sum) + mx - t_label;                     // -log softmax(pred)[label], the same in every lane
+    const float inv_sum = 1.0f / sum;
+    for (int c = lane; c < p.Np; c += 64) {
+      float d = 0.f;
+      if (c < p.n_out) {
+        const float t = row[c];
+        d = (__expf(t - mx) * inv_sum - (c == label ? 1.0f : 0.f)) * p.inv_b * dact_from_output(t, p.act);
+      }
+      drow[c] = d;
+    }
+  }
+  if (lane == 0) ce_wave[w] = loss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float part = ((ce_wave[0] + ce_wave[1]) + (ce_wave[2] + ce_wave[3])) * p.inv_b;
+    p.ce_part[blockIdx.x] = part;
+    if (p.ce_acc) p.ce_acc[blockIdx.x] += static_cast<double>(part);
+  }
+}
+
 struct BwdParams {
   const float *h_in;     // [Bp][Kp] this layer's input activations (column K = 1)
   const float *dz;       // [Bp][Np]
@@ -323,7 +379,7 @@ __global__ __launch_bounds__(256) void dense_cost_kernel(const CostParams p) {
 }  // namespace nnv
 
 struct nnv_dense_train_handle {
-  int32_t L, act, B, Bp, n_out, device;
+  int32_t L, act, B, Bp, n_out, device, loss;
   int32_t K[nnv::kMaxL], N[nnv::kMaxL], Kp[nnv::kMaxL], Np[nnv::kMaxL];
   uint32_t reg_mask;
   float lr, beta_reg;
@@ -362,7 +418,7 @@ nnv_status dense_fwd_bwd(nnv_dense_train_handle *h, const int32_t *labels, bool 
     p.B = h->B;
     p.ones_col = last ? -1 : h->N[l];
     p.act = h->act;
-    if (last) {
+    if (last && h->loss == NNV_LOSS_SIGMOID_CE) {
       p.labels = labels;
       p.dz = h->dz[l];
       p.n_out = h->n_out;
@@ -371,6 +427,12 @@ nnv_status dense_fwd_bwd(nnv_dense_train_handle *h, const int32_t *labels, bool 
       p.ce_acc = training_step ? h->ce_acc : nullptr;
     }
     hipLaunchKernelGGL(nnv::dense_fwd_kernel, dim3((h->Bp / 32) * (h->Np[l] / 32)), dim3(nnv::kThreads), 0, s, p);
+  }
+  if (h->loss == NNV_LOSS_SOFTMAX_CE) {
+    const int last = h->L - 1;
+    nnv::SoftmaxLossParams p{h->h[h->L], labels, h->dz[last], h->B, h->Np[last], h->n_out, h->act,
+                             1.0f / static_cast<float>(h->B), h->ce_part, training_step ? h->ce_acc : nullptr};
+    hipLaunchKernelGGL(nnv::dense_softmax_loss_kernel, dim3((h->B + 3) / 4), dim3(256), 0, s, p);
   }
   for (int l = h->L - 1; l >= 0; --l) {
     nnv::BwdParams p{h->h[l], h->dz[l], h->w + h->off_w[l], h->dw + h->off_w[l], l > 0 ? h->dz[l - 1] : nullptr,
@@ -435,7 +497,10 @@ int32_t nnv_dense_train_create(const nnv_dense_train_desc *d, nnv_dense_train_ha
   if (!(d->learning_rate > 0.f) || d->n_extra < 0 || (d->n_extra > 0 && !d->extra_host)) return NNV_ERR_INVALID_ARGUMENT;
   for (int l = 0; l <= d->n_layers; ++l)
     if (d->dims[l] < 1 || d->dims[l] > NNV_WIDE_MAX_WIDTH) return NNV_ERR_UNSUPPORTED_SHAPE;
-  if (d->dims[d->n_layers] > 32) return NNV_ERR_UNSUPPORTED_SHAPE;   // the loss kernel's output tile
+  if (d->loss != NNV_LOSS_SIGMOID_CE && d->loss != NNV_LOSS_SOFTMAX_CE) return NNV_ERR_INVALID_ARGUMENT;
+  // sigmoid cross-entropy lives in the last forward launch's epilogue (one 32-wide tile); softmax has its own launch
+  if (d->loss == NNV_LOSS_SIGMOID_CE && d->dims[d->n_layers] > 32) return NNV_ERR_UNSUPPORTED_SHAPE;
+  if (d->dims[d->n_layers] > NNV_WIDE_MAX_CLASSES) return NNV_ERR_UNSUPPORTED_SHAPE;
   for (int l = 0; l < d->n_layers; ++l)
     if (!d->W_host[l] || !d->b_host[l]) return NNV_ERR_INVALID_ARGUMENT;
   int dev = 0;
@@ -450,6 +515,7 @@ int32_t nnv_dense_train_create(const nnv_dense_train_desc *d, nnv_dense_train_ha
   h->B = d->batch_size;
   h->Bp = round_up32(d->batch_size);
   h->n_out = d->dims[d->n_layers];
+  h->loss = d->loss;
   h->device = dev;
   h->reg_mask = d->reg_layer_mask;
   h->lr = d->learning_rate;
@@ -469,7 +535,7 @@ int32_t nnv_dense_train_create(const nnv_dense_train_desc *d, nnv_dense_train_ha
   h->adam_blocks = static_cast<int32_t>((h->n_params + 255) / 256);
   int64_t act_floats = static_cast<int64_t>(h->Bp) * h->Kp[0];
   for (int l = 0; l < h->L; ++l) act_floats += 2 * static_cast<int64_t>(h->Bp) * h->Np[l];   // h[l + 1] and dz[l]
-  h->n_row_tiles = h->Bp / 32;
+  h->n_row_tiles = d->loss == NNV_LOSS_SOFTMAX_CE ? (h->B + 3) / 4 : h->Bp / 32;   // workgroups that write a share of the cost
   const int64_t total = 5 * h->n_params + act_floats + h->adam_blocks + h->n_row_tiles + 8 +
                         2 * (static_cast<int64_t>(h->n_row_tiles) + h->adam_blocks);
   if (hipMalloc(reinterpret_cast<void **>(&h->dev), total * sizeof(float)) != hipSuccess) {

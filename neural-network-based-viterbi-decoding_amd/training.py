@@ -344,20 +344,23 @@ class NativeFNNTrainer:
 class NativeDenseTrainer:
     """The training step of the reference's bit-wise and sliding-window decoders as 2 L + 1 hand-written HIP launches
     per step (C ABI ``nnv_dense_train_*``, csrc/nnv_dense_train.hip) instead of ~60 PyTorch-autograd kernels: a dense
-    network of 1..5 layers with the activation after EVERY layer, mean sigmoid cross-entropy on the activated outputs,
-    beta * l2_loss of the layers in ``reg_layers``, TF-1 Adam (src/fnn_viterbi_bitwise.py:388-397,438-452;
+    network of 1..5 layers with the activation after EVERY layer, mean sigmoid cross-entropy on the activated outputs
+    (``loss="softmax"``: the feed-forward decoder's softmax cross-entropy on them, src/fnn_viterbi.py:549-553, for class
+    counts K7 does not take), beta * l2_loss of the layers in ``reg_layers``, TF-1 Adam (src/fnn_viterbi_bitwise.py:388-397,438-452;
     src/fnn_viterbi_seq_predict.py:404-412,475-489).  ``extra`` holds variables that only the regulariser names (the
     bit-wise decoder's unused ``h2``).  Labels are class indices.  Rows of a step may be overlapping windows of one
     stream (``row_stride``).  Checked against oracle/dense_train_oracle.py (tests/test_dense_trainer.py)."""
 
     ACT = {"tanh": 0, "relu": 1}
+    LOSS = {"sigmoid": 0, "softmax": 1}     # nnv_loss
 
     @staticmethod
-    def eligible(Ws, n_out: int) -> bool:
-        return torch.cuda.is_available() and 1 <= len(Ws) <= 5 and n_out <= 32 and os.environ.get("NNV_TRAINER") != "autograd"
+    def eligible(Ws, n_out: int, loss: str = "sigmoid") -> bool:
+        return (torch.cuda.is_available() and 1 <= len(Ws) <= 5 and n_out <= (32 if loss == "sigmoid" else 65536)
+                and os.environ.get("NNV_TRAINER") != "autograd")
 
     def __init__(self, Ws, bs, activation: str, learning_rate: float, beta_regularization: float, batch_size: int,
-                 reg_layers=(0, 1), extra=None, device=None):
+                 reg_layers=(0, 1), extra=None, device=None, loss: str = "sigmoid"):
         import ctypes
         from . import _cabi
         self._cabi, self._ctypes = _cabi, ctypes
@@ -378,6 +381,7 @@ class NativeDenseTrainer:
         d.activation, d.batch_size = self.ACT[activation], self.batch_size
         d.learning_rate, d.beta_regularization = float(learning_rate), float(beta_regularization)
         d.reg_layer_mask = sum(1 << l for l in reg_layers if l < len(Ws))
+        d.loss = self.LOSS[loss]
         d.extra_host, d.n_extra = (ex.ctypes.data if self.n_extra else None), self.n_extra
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -533,7 +537,8 @@ def train_network(config, training_set: np.ndarray, training_labels: np.ndarray,
                   use_dropout: bool = False, keep_prob: float = 0.5,
                   verbose: bool = True) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
     """Returns trained copies of (weights, biases), keyed like the inputs.  On an MI355X the reference's architecture
-    trains through the two-kernel step (:class:`NativeFNNTrainer`); other shapes, and ``NNV_TRAINER=autograd``, through
+    trains through the two-kernel step (:class:`NativeFNNTrainer`, <= 256 classes), other class counts and depths
+    without dropout through the dense kernels with the softmax loss (:class:`NativeDenseTrainer`); the rest, and ``NNV_TRAINER=autograd``, through
     PyTorch autograd (:class:`FNNTrainer`), one HIP-graph replay per step."""
     bs = int(config.batch_size)
     total_batch = int(config.num_training_samples / bs)
@@ -553,6 +558,25 @@ def train_network(config, training_set: np.ndarray, training_labels: np.ndarray,
         out = nt.export()
         nt.close()
         return out
+    w_keys = [k for k in ("h1", "h2", "h3", "out") if k in weights]
+    n_out = int(np.asarray(weights["out"]).shape[1])
+    if (not use_dropout and total_batch > 0 and NativeDenseTrainer.eligible(w_keys, n_out, "softmax")):
+        # K8 with the softmax loss (csrc/nnv_dense_train.hip): feed-forward decoders K7 does not take (more than 256 classes,
+        # other hidden widths), 2 L + 2 launches per step
+        b_keys = [{"h1": "b1", "h2": "b2", "h3": "b3", "out": "out"}[k] for k in w_keys]
+        nd = NativeDenseTrainer([weights[k] for k in w_keys], [biases[k] for k in b_keys], "tanh", config.learning_rate,
+                                config.beta_regularization, bs, reg_layers=tuple(range(len(w_keys) - 1)), loss="softmax")
+        n = total_batch * bs
+        x_all = torch.as_tensor(np.asarray(training_set)[:n], dtype=torch.float32, device=nd.device).contiguous()
+        y = np.asarray(training_labels)[:n]
+        lab = torch.as_tensor(np.argmax(y, axis=1) if y.ndim == 2 else y, device=nd.device).to(torch.int32).contiguous()
+        for epoch in range(int(config.training_epochs)):
+            nd.steps(x_all, lab, total_batch)
+            if verbose and epoch % int(getattr(config, "display_step", 1)) == 0:
+                print(f"Epoch: {epoch + 1:04d} | cost = {nd.export(want_cost_sum=True)[3] / total_batch:.9f}")
+        Ws, Bs, _ = nd.export()
+        nd.close()
+        return dict(zip(w_keys, Ws)), dict(zip(b_keys, Bs))
     tr = FNNTrainer(weights, biases, config.learning_rate, config.beta_regularization,
                     use_dropout=use_dropout, keep_prob=keep_prob)
     dev = tr.device

@@ -212,3 +212,74 @@ def test_sliding_window_training_native_and_autograd_agree():
         assert np.abs(res[None][0][k] - res["autograd"][0][k]).max() < 2e-5, k
     for k in res[None][1]:
         assert np.abs(res[None][1][k] - res["autograd"][1][k]).max() < 2e-5, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,batch", [([18, 128, 64, 32, 512], 256), ([20, 128, 64, 32, 1024], 100), ([14, 128, 64, 100], 37),
+                                        ([9, 128, 33], 64)])
+def test_native_dense_softmax_step_against_the_fnn_restatement(dims, batch):
+    """K8 with the feed-forward decoder's loss (softmax cross-entropy on the tanh outputs + beta l2 of the hidden layers,
+    src/fnn_viterbi.py:549-559) at class counts K7 does not take (512, 1024) and at other depths: cost, all gradients,
+    three steps against oracle/train_oracle.py."""
+    import torch
+    from oracle import train_oracle as TO
+    from nnviterbi_amd.training import NativeDenseTrainer
+    rng = np.random.RandomState(dims[-1] + batch)
+    L = len(dims) - 1
+    wk, bk = ["h1", "h2", "h3"][:L - 1] + ["out"], ["b1", "b2", "b3"][:L - 1] + ["out"]
+    w = {k: (rng.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i, k in enumerate(wk)}
+    bd = {k: (rng.randn(dims[i + 1]) * 0.1).astype(np.float32) for i, k in enumerate(bk)}
+    x = rng.randn(3 * batch, dims[0]).astype(np.float32)
+    lab = rng.randint(0, dims[-1], 3 * batch).astype(np.int32)
+    y = np.eye(dims[-1], dtype=np.float32)[lab]
+    ref = TO.Trainer(w, bd, 1e-4, 1e-3)
+    nt = NativeDenseTrainer([w[k] for k in wk], [bd[k] for k in bk], "tanh", 1e-4, 1e-3, batch,
+                            reg_layers=tuple(range(L - 1)), loss="softmax")
+    xd, ld = torch.tensor(x, device="cuda"), torch.tensor(lab, device="cuda")
+    cost, gW, gb, _ = nt.gradients(xd, ld)
+    rcost, dW, db = ref.gradients(x[:batch], y[:batch])
+    assert abs(cost - rcost) < 2e-6, (cost, rcost)
+    for a, b in zip(gW + gb, dW + db):
+        assert np.abs(a.astype(np.float64) - b).max() < TOL
+    costs = nt.steps(xd, ld, 3, want_costs=True).cpu().numpy()
+    rc = [ref.step(x[i * batch:(i + 1) * batch], y[i * batch:(i + 1) * batch]) for i in range(3)]
+    assert np.abs(costs - np.array(rc)).max() < 2e-6
+    got_w, got_b, _, cost_sum = nt.export(want_cost_sum=True)
+    assert abs(cost_sum - sum(rc)) < 1e-5
+    for a, b in zip(got_w + got_b, ref.Ws + ref.bs):
+        assert np.abs(a.astype(np.float64) - b).max() < 5e-6
+    nt.close()
+
+
+@pytest.mark.gpu
+def test_train_network_beyond_256_classes_runs_the_dense_kernels_and_agrees_with_autograd():
+    """fnn_viterbi at block_length 9 (512 classes: K7 does not take it): train_network goes through K8 with the softmax
+    loss and prints the same costs as the PyTorch-autograd trainer (1e-5), the weights agree to 2e-5."""
+    from nnviterbi_amd import fnn_viterbi as fv, training
+    cfg = fv.DecoderConfig(block_length=9, training_epochs=2, batch_size=128)
+    rng = np.random.RandomState(3)
+    n = 128 * 6
+    x = rng.randn(n, cfg.n_input).astype(np.float32)
+    y = np.eye(cfg.n_classes, dtype=np.float32)[rng.randint(0, cfg.n_classes, n)]
+    cfg.num_training_samples = n
+    res = {}
+    for mode in (None, "autograd"):
+        old = os.environ.get("NNV_TRAINER")
+        if mode:
+            os.environ["NNV_TRAINER"] = mode
+        else:
+            os.environ.pop("NNV_TRAINER", None)
+        try:
+            w0, b0 = fv.initialize_weights(cfg, rng=np.random.RandomState(5))
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                res[mode] = training.train_network(cfg, x, y, w0, b0) + (buf.getvalue(),)
+        finally:
+            if old is None:
+                os.environ.pop("NNV_TRAINER", None)
+            else:
+                os.environ["NNV_TRAINER"] = old
+    costs = lambda s: [float(l.split("=")[1]) for l in s.splitlines() if l.startswith("Epoch:")]
+    assert len(costs(res[None][2])) == 2 and np.abs(np.array(costs(res[None][2])) - np.array(costs(res["autograd"][2]))).max() < 1e-5
+    for k in res[None][0]:
+        assert np.abs(res[None][0][k] - res["autograd"][0][k]).max() < 2e-5, k
